@@ -1,0 +1,314 @@
+"""ctypes binding of include/crt_gpu.h (the C ABI of libcrt_gpu.so).
+
+This is the host-side mirror of the reference's scene-intersection interface
+(`intersectTest` / `shadowIntersectTest`, /root/reference/intersect.h:365,:443 over a
+`SceneObjects` handle, scene/scenedata.h:20-28), batched: a `Scene` is built once from a list
+of objects in insertion order and answers closest-hit and any-hit queries for arrays of rays.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcrt_gpu.so")
+
+# enums (include/crt_gpu.h; same values as shapes/objecttype.h:4-18 and scene/scenedata.h:12-18)
+SPHERE, PLANE, RECTANGLE, AABOX, TRIANGLE, GENERICOPENCYLINDER, DISK, GENERICTORUS, INSTANCED, COMPOUND, \
+    FLAT_TRIANGLE, SMOOTH_TRIANGLE = range(12)
+ACCEL_NONE, ACCEL_GRID, ACCEL_BVH, ACCEL_BVH4 = range(4)
+ACCEL_NAMES = {"NONE": ACCEL_NONE, "GRID": ACCEL_GRID, "BVH": ACCEL_BVH, "BVH4": ACCEL_BVH4}
+TRAVERSE_AUTO, TRAVERSE_PRUNED, TRAVERSE_EXACT = range(3)
+TRI_TYPES = (TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE)
+
+K_EPSILON = np.float32(0.000007)
+TMAX = np.float32(3.402823466e+38)
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("obj", "<i4"), ("part", "<i4"), ("beta", "<f4"), ("gamma", "<f4")])
+assert HIT_DTYPE.itemsize == 20
+
+
+class CrtShape(C.Structure):
+    _fields_ = [("type", C.c_int32), ("inner", C.c_int32), ("first_part", C.c_int32), ("num_parts", C.c_int32),
+                ("p", C.c_float * 12), ("inv_xform", C.c_float * 16)]
+
+
+SHAPE_DTYPE = np.dtype([("type", "<i4"), ("inner", "<i4"), ("first_part", "<i4"), ("num_parts", "<i4"),
+                        ("p", "<f4", (12,)), ("inv_xform", "<f4", (16,))])
+assert SHAPE_DTYPE.itemsize == C.sizeof(CrtShape) == 128
+
+
+class CrtSceneInput(C.Structure):
+    _fields_ = [("num_obj", C.c_int32), ("obj_type", C.c_void_p), ("obj_ref", C.c_void_p),
+                ("tri_verts", C.c_void_p), ("num_tris", C.c_int32),
+                ("shapes", C.c_void_p), ("num_shapes", C.c_int32)]
+
+
+class CrtBvh4Node(C.Structure):
+    _fields_ = [("bbox", C.c_float * 24), ("child", C.c_int32 * 4), ("type", C.c_int8 * 4),
+                ("axis", C.c_uint8), ("pad", C.c_uint8 * 11)]
+
+
+NODE4_DTYPE = np.dtype([("bbox", "<f4", (24,)), ("child", "<i4", (4,)), ("type", "i1", (4,)),
+                        ("axis", "u1"), ("pad", "u1", (11,))])
+NODE2_DTYPE = np.dtype([("bmin", "<f4", (3,)), ("bmax", "<f4", (3,)), ("left", "<i4"), ("right", "<i4")])
+assert NODE4_DTYPE.itemsize == C.sizeof(CrtBvh4Node) == 128 and NODE2_DTYPE.itemsize == 32
+
+
+class CrtGrid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("num_cells", C.c_int32),
+                ("wx", C.c_float), ("wy", C.c_float), ("wz", C.c_float),
+                ("bmin", C.c_float * 3), ("bmax", C.c_float * 3)]
+
+
+class CrtSceneDesc(C.Structure):
+    _fields_ = [("accel", C.c_int32), ("num_obj", C.c_int32), ("num_non_grid_obj", C.c_int32),
+                ("obj_type", C.c_void_p), ("obj_ref", C.c_void_p), ("obj_id", C.c_void_p),
+                ("tri_verts", C.c_void_p), ("num_tris", C.c_int32),
+                ("shapes", C.c_void_p), ("num_shapes", C.c_int32),
+                ("nodes4", C.c_void_p), ("num_nodes4", C.c_int32),
+                ("nodes2", C.c_void_p), ("num_nodes2", C.c_int32),
+                ("grid", CrtGrid), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p)]
+
+
+class CrtCounters(C.Structure):
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
+
+
+# every symbol include/crt_gpu.h declares
+EXPORTS = [
+    "crt_build_scene", "crt_built_scene_desc", "crt_built_scene_destroy",
+    "crt_device_count", "crt_scene_create", "crt_scene_destroy",
+    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode",
+    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
+    "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
+    "crt_scene_last_kernel_ms", "crt_strerror", "crt_last_hip_error",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libcrt_gpu.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "craytracer_amd: %s is missing -- build it with `make -C craytracer_amd/csrc` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.crt_build_scene.argtypes = [C.POINTER(CrtSceneInput), C.c_int, C.POINTER(vp)]
+    L.crt_built_scene_desc.argtypes = [vp]
+    L.crt_built_scene_desc.restype = C.POINTER(CrtSceneDesc)
+    L.crt_built_scene_destroy.argtypes = [vp]
+    L.crt_built_scene_destroy.restype = None
+    L.crt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.crt_scene_create.argtypes = [C.c_int, C.POINTER(CrtSceneDesc), C.POINTER(vp)]
+    L.crt_scene_destroy.argtypes = [vp]
+    L.crt_scene_destroy.restype = None
+    L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
+    L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.crt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
+    L.crt_shadow_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.crt_intersect_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    L.crt_shadow_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.crt_scene_enable_counters.argtypes = [vp, C.c_int]
+    L.crt_scene_get_counters.argtypes = [vp, C.POINTER(CrtCounters)]
+    L.crt_scene_reset_counters.argtypes = [vp]
+    L.crt_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crt_strerror.argtypes = [C.c_int]
+    L.crt_strerror.restype = C.c_char_p
+    L.crt_last_hip_error.argtypes = []
+    L.crt_last_hip_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class CrtError(RuntimeError):
+    def __init__(self, code, where):
+        L = lib()
+        msg = "%s: %s (%d)" % (where, L.crt_strerror(code).decode(), code)
+        hip = L.crt_last_hip_error().decode()
+        if hip:
+            msg += " [" + hip + "]"
+        super().__init__(msg)
+        self.code = code
+
+
+def _check(code, where):
+    if code != 0:
+        raise CrtError(code, where)
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class SceneInput:
+    """Objects in insertion order (what SceneObjects_push_obj accumulates, scenedata.h:40-48)."""
+
+    def __init__(self, tri_verts=None, shapes=None, obj_type=None, obj_ref=None):
+        self.tri_verts = np.ascontiguousarray(
+            np.zeros((0, 9), np.float32) if tri_verts is None else tri_verts, dtype=np.float32).reshape(-1, 9)
+        self.shapes = np.ascontiguousarray(
+            np.zeros(0, SHAPE_DTYPE) if shapes is None else shapes, dtype=SHAPE_DTYPE)
+        if obj_type is None:
+            self.obj_type = None
+            self.obj_ref = None
+            self.num_obj = len(self.tri_verts)
+        else:
+            self.obj_type = np.ascontiguousarray(obj_type, dtype=np.int32)
+            self.obj_ref = np.ascontiguousarray(obj_ref, dtype=np.int32)
+            self.num_obj = len(self.obj_type)
+
+    def c_struct(self):
+        s = CrtSceneInput()
+        s.num_obj = self.num_obj
+        s.obj_type = _ptr(self.obj_type) if self.obj_type is not None else None
+        s.obj_ref = _ptr(self.obj_ref) if self.obj_ref is not None else None
+        s.tri_verts = _ptr(self.tri_verts)
+        s.num_tris = len(self.tri_verts)
+        s.shapes = _ptr(self.shapes)
+        s.num_shapes = len(self.shapes)
+        return s
+
+
+def _view(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype)
+    dt = np.dtype(dtype)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n)
+
+
+class BuiltScene:
+    """mvNonGridObjToStart + buildSceneAccel (scenedata.h:368, buildscene.h:698) on the host."""
+
+    def __init__(self, scene_input, accel):
+        self._h = C.c_void_p()
+        self._input = scene_input            # keep arrays alive during the call only; build copies them
+        cin = scene_input.c_struct()
+        _check(lib().crt_build_scene(C.byref(cin), int(accel), C.byref(self._h)), "crt_build_scene")
+        self.desc = lib().crt_built_scene_desc(self._h).contents
+        self.accel = int(accel)
+
+    # numpy views into the built arrays (valid while this object lives)
+    @property
+    def obj_id(self):
+        return _view(self.desc.obj_id, self.desc.num_obj, np.int32)
+
+    @property
+    def obj_type(self):
+        return _view(self.desc.obj_type, self.desc.num_obj, np.int32)
+
+    @property
+    def obj_ref(self):
+        return _view(self.desc.obj_ref, self.desc.num_obj, np.int32)
+
+    @property
+    def nodes4(self):
+        return _view(self.desc.nodes4, self.desc.num_nodes4, NODE4_DTYPE)
+
+    @property
+    def nodes2(self):
+        return _view(self.desc.nodes2, self.desc.num_nodes2, NODE2_DTYPE)
+
+    @property
+    def cell_start(self):
+        return _view(self.desc.cell_start, self.desc.grid.num_cells + 1 if self.accel == ACCEL_GRID else 0, np.int32)
+
+    @property
+    def cell_items(self):
+        cs = self.cell_start
+        return _view(self.desc.cell_items, int(cs[-1]) if len(cs) else 0, np.int32)
+
+    def close(self):
+        if self._h:
+            lib().crt_built_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """A scene resident in the HBM of one GPU; answers batches of rays."""
+
+    def __init__(self, built, device=0):
+        self._h = C.c_void_p()
+        self.device = device
+        _check(lib().crt_scene_create(int(device), C.byref(built.desc), C.byref(self._h)), "crt_scene_create")
+
+    def set_traverse_mode(self, mode):
+        _check(lib().crt_scene_set_traverse_mode(self._h, int(mode)), "crt_scene_set_traverse_mode")
+
+    def traverse_mode(self):
+        m = C.c_int()
+        _check(lib().crt_scene_get_traverse_mode(self._h, C.byref(m)), "crt_scene_get_traverse_mode")
+        return m.value
+
+    def intersect(self, rays):
+        """n x intersectTest.  rays: float32 [n, 6] (origin, direction).  Returns HIT_DTYPE[n]."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.empty(len(rays), HIT_DTYPE)
+        _check(lib().crt_intersect_batch(self._h, _ptr(rays), len(rays), _ptr(hits)), "crt_intersect_batch")
+        return hits
+
+    def shadow(self, rays, light_dist):
+        """n x shadowIntersectTest; returns (t float32[n], occluded bool[n])."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        ld = np.ascontiguousarray(light_dist, dtype=np.float32).reshape(-1)
+        assert len(ld) == len(rays)
+        t = np.empty(len(rays), np.float32)
+        occ = np.empty(len(rays), np.uint8)
+        _check(lib().crt_shadow_batch(self._h, _ptr(rays), _ptr(ld), len(rays), _ptr(t), _ptr(occ)), "crt_shadow_batch")
+        return t, occ.astype(bool)
+
+    def intersect_dev(self, d_rays, n, d_hits, stream=None):
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
+        _check(lib().crt_intersect_batch_dev(self._h, d_rays, n, d_hits, stream), "crt_intersect_batch_dev")
+
+    def shadow_dev(self, d_rays, d_light_dist, n, d_t, d_occ, stream=None):
+        _check(lib().crt_shadow_batch_dev(self._h, d_rays, d_light_dist, n, d_t, d_occ, stream), "crt_shadow_batch_dev")
+
+    def enable_counters(self, on=True):
+        _check(lib().crt_scene_enable_counters(self._h, 1 if on else 0), "crt_scene_enable_counters")
+
+    def counters(self):
+        c = CrtCounters()
+        _check(lib().crt_scene_get_counters(self._h, C.byref(c)), "crt_scene_get_counters")
+        return {"rays_closest": c.rays_closest, "rays_shadow": c.rays_shadow,
+                "nodes_visited": c.nodes_visited, "prims_tested": c.prims_tested}
+
+    def reset_counters(self):
+        _check(lib().crt_scene_reset_counters(self._h), "crt_scene_reset_counters")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(lib().crt_scene_last_kernel_ms(self._h, C.byref(ms)), "crt_scene_last_kernel_ms")
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().crt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    n = C.c_int()
+    _check(lib().crt_device_count(C.byref(n)), "crt_device_count")
+    return n.value

@@ -1,0 +1,505 @@
+/*
+ * crt_gpu.hip -- the C ABI of include/crt_gpu.h over the kernels in crt_kernels.h.
+ *
+ * Replaces, for the intersect step only, the reference's per-pixel worker loop
+ * (parallel.h + main.cpp:88-149) that calls intersectTest / shadowIntersectTest
+ * (intersect.h:365,:443) one ray at a time: the host hands over a batch of rays and gets
+ * a batch of hit records back.
+ */
+#include "crt_kernels.h"
+
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <new>
+
+namespace {
+
+thread_local char g_hip_err[256] = "";
+
+bool hip_ok(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return true;
+    snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    return false;
+}
+#define HIPCHK(call) do { if (!hip_ok((call), #call)) return CRT_E_HIP; } while (0)
+
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int dev) : prev(-1), ok(false)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hip_ok(hipSetDevice(dev), "hipSetDevice");
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+} // namespace
+
+struct crt_scene {
+    int device;
+    DevScene dev;
+    bool tri_only;            /* every object is a triangle type */
+    bool accel_tri_only;      /* every object below the accelerator is a triangle type */
+    int mode;                 /* requested crt_traverse_mode */
+    bool count;
+    int num_cus;
+    /* device allocations */
+    void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_cell_start; void* d_cell_items;
+    unsigned long long* d_counters;
+    unsigned* d_queue_head;   /* 256 B, word 0 used */
+    unsigned* d_ovf_word; float* d_ovf_key; unsigned ovf_threads;
+    hipEvent_t ev_start, ev_stop; bool ev_valid;
+};
+
+namespace {
+
+int resolved_mode(const crt_scene* s)
+{
+    if (s->mode == CRT_TRAVERSE_AUTO) return s->accel_tri_only ? CRT_TRAVERSE_PRUNED : CRT_TRAVERSE_EXACT;
+    return s->mode;
+}
+
+/* levels below (and including) node `root` of the flat QBVH / BVH */
+int depth4(const crt_scene_desc* d)
+{
+    if (d->num_nodes4 == 0) return 0;
+    std::vector<std::pair<int, int> > stack;
+    stack.push_back(std::make_pair(0, 1));
+    int best = 0;
+    while (!stack.empty()) {
+        std::pair<int, int> e = stack.back(); stack.pop_back();
+        if (e.second > best) best = e.second;
+        const crt_bvh4_node& n = d->nodes4[e.first];
+        for (int c = 0; c < 4; c++) if (n.type[c] == -1) stack.push_back(std::make_pair(n.child[c], e.second + 1));
+    }
+    return best;
+}
+int depth2(const crt_scene_desc* d)
+{
+    if (d->num_nodes2 == 0) return 0;
+    std::vector<std::pair<int, int> > stack;
+    stack.push_back(std::make_pair(0, 1));
+    int best = 0;
+    while (!stack.empty()) {
+        std::pair<int, int> e = stack.back(); stack.pop_back();
+        if (e.second > best) best = e.second;
+        const crt_bvh2_node& n = d->nodes2[e.first];
+        if (n.left >= 0) { stack.push_back(std::make_pair(n.left, e.second + 1)); stack.push_back(std::make_pair(n.right, e.second + 1)); }
+    }
+    return best;
+}
+
+int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
+{
+    if (!d || d->num_obj < 0 || d->num_non_grid_obj < 0 || d->num_non_grid_obj > d->num_obj) return CRT_E_INVALID;
+    if (d->accel < CRT_ACCEL_NONE || d->accel > CRT_ACCEL_BVH4) return CRT_E_INVALID;
+    if (d->num_obj >= (1 << 28)) return CRT_E_TOOBIG;
+    if (d->num_obj > 0 && (!d->obj_type || !d->obj_ref || !d->obj_id)) return CRT_E_INVALID;
+    for (int i = 0; i < d->num_obj; i++) {
+        int t = d->obj_type[i], r = d->obj_ref[i];
+        if (t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE) {
+            if (r < 0 || r >= d->num_tris || !d->tri_verts) return CRT_E_INVALID;
+        } else {
+            if (t < 0 || t > CRT_COMPOUND || r < 0 || r >= d->num_shapes || !d->shapes || d->shapes[r].type != t) return CRT_E_INVALID;
+        }
+    }
+    /* shape nesting the kernels handle: simple | compound{simple} | instanced{simple | compound{simple}} */
+    for (int i = 0; i < d->num_shapes; i++) {
+        const crt_shape& sh = d->shapes[i];
+        if (sh.type == CRT_INSTANCED) {
+            if (sh.inner < 0 || sh.inner >= d->num_shapes) return CRT_E_INVALID;
+            if (d->shapes[sh.inner].type == CRT_INSTANCED) return CRT_E_UNSUPPORTED;
+        } else if (sh.type == CRT_COMPOUND) {
+            if (sh.first_part < 0 || sh.num_parts < 0 || sh.first_part + sh.num_parts > d->num_shapes) return CRT_E_INVALID;
+            for (int k = 0; k < sh.num_parts; k++) {
+                int pt = d->shapes[sh.first_part + k].type;
+                if (pt == CRT_INSTANCED || pt == CRT_COMPOUND) return CRT_E_UNSUPPORTED;
+            }
+        } else if (sh.type < 0 || sh.type > CRT_COMPOUND || sh.type == CRT_TRIANGLE) return CRT_E_INVALID;
+    }
+    int na = d->num_obj - d->num_non_grid_obj;
+    *d4 = 0; *d2 = 0;
+    if (d->accel == CRT_ACCEL_BVH4 && na > 0) {
+        if (!d->nodes4 || d->num_nodes4 < 1) return CRT_E_INVALID;
+        for (int i = 0; i < d->num_nodes4; i++) for (int c = 0; c < 4; c++) {
+            const crt_bvh4_node& n = d->nodes4[i];
+            if (n.type[c] == -1) { if (n.child[c] <= i || n.child[c] >= d->num_nodes4) return CRT_E_INVALID; }
+            else if (n.type[c] < 0 || n.type[c] > 4 || n.child[c] < 0 || n.child[c] + n.type[c] > d->num_obj) return CRT_E_INVALID;
+        }
+        *d4 = depth4(d);
+        if (3 * *d4 + 1 > CRT_STACK_MAX) return CRT_E_TOOBIG;       /* per-lane stack: <= 3 pending siblings per level */
+    }
+    if (d->accel == CRT_ACCEL_BVH && na > 0) {
+        if (!d->nodes2 || d->num_nodes2 < 1) return CRT_E_INVALID;
+        for (int i = 0; i < d->num_nodes2; i++) {
+            const crt_bvh2_node& n = d->nodes2[i];
+            if (n.left < 0) { if (n.right < 0 || n.right >= d->num_obj) return CRT_E_INVALID; }
+            else if (n.left <= i || n.left >= d->num_nodes2 || n.right <= i || n.right >= d->num_nodes2) return CRT_E_INVALID;
+        }
+        *d2 = depth2(d);
+        if (*d2 + 1 > CRT_STACK_MAX) return CRT_E_TOOBIG;
+    }
+    if (d->accel == CRT_ACCEL_GRID) {
+        const crt_grid& g = d->grid;
+        if (g.nx < 1 || g.ny < 1 || g.nz < 1 || (long long)g.nx * g.ny * g.nz != g.num_cells) return CRT_E_INVALID;
+        if (!d->cell_start) return CRT_E_INVALID;
+        if (d->cell_start[0] != 0) return CRT_E_INVALID;
+        for (int c = 0; c < g.num_cells; c++) if (d->cell_start[c+1] < d->cell_start[c]) return CRT_E_INVALID;
+        int total = d->cell_start[g.num_cells];
+        if (total > 0 && !d->cell_items) return CRT_E_INVALID;
+        for (int k = 0; k < total; k++) if (d->cell_items[k] < 0 || d->cell_items[k] >= d->num_obj) return CRT_E_INVALID;
+    }
+    return CRT_OK;
+}
+
+template <class T>
+int upload(void** dst, const std::vector<T>& v)
+{
+    *dst = 0;
+    size_t bytes = v.size() * sizeof(T);
+    if (bytes == 0) bytes = 256;                                   /* keep pointers non-null */
+    if (!hip_ok(hipMalloc(dst, bytes), "hipMalloc")) return CRT_E_NOMEM;
+    if (!v.empty() && !hip_ok(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D")) return CRT_E_HIP;
+    return CRT_OK;
+}
+
+void free_scene(crt_scene* s)
+{
+    if (!s) return;
+    void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
+                     s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (s->ev_valid) { (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); }
+    delete s;
+}
+
+/* ---- launch ------------------------------------------------------------------------- */
+
+template <class K>
+int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream)
+{
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CRT_BLOCK, 0));
+    if (per_cu < 1) per_cu = 1;
+    unsigned blocks = (unsigned)(s->num_cus * per_cu);
+    unsigned need = (la.n + CRT_BLOCK - 1) / CRT_BLOCK;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    if (blocks * CRT_BLOCK > s->ovf_threads) blocks = s->ovf_threads / CRT_BLOCK;   /* overflow area is sized for this many */
+    la.queue_head = s->d_queue_head;
+    la.ovf_word = s->d_ovf_word;
+    la.ovf_key = s->d_ovf_key;
+    la.grid_threads = s->ovf_threads;
+    HIPCHK(hipMemsetAsync(s->d_queue_head, 0, 256, stream));
+    HIPCHK(hipEventRecord(s->ev_start, stream));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev_stop, stream));
+    return CRT_OK;
+}
+
+template <bool TRI_ONLY, bool COUNT>
+int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st)
+{
+    const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
+    switch (s->dev.accel) {
+    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest_exact<TRI_ONLY, COUNT>, la, st)
+                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT>, la, st);
+    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, false>, la, st)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false>, la, st);
+    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st);
+    default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st);
+    }
+}
+template <bool TRI_ONLY, bool COUNT>
+int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
+{
+    const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
+    switch (s->dev.accel) {
+    case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st);
+    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, true>, la, st)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true>, la, st);
+    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
+    default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* crt_strerror(int code)
+{
+    switch (code) {
+    case CRT_OK: return "ok";
+    case CRT_E_INVALID: return "invalid argument or inconsistent scene description";
+    case CRT_E_NOMEM: return "out of host or device memory";
+    case CRT_E_HIP: return "HIP runtime call failed (see crt_last_hip_error)";
+    case CRT_E_UNSUPPORTED: return "unsupported request";
+    case CRT_E_TOOBIG: return "size beyond a documented limit";
+    case CRT_E_NODEVICE: return "no usable gfx950 device";
+    default: return "unknown error code";
+    }
+}
+const char* crt_last_hip_error(void) { return g_hip_err; }
+
+int crt_device_count(int* count)
+{
+    if (!count) return CRT_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return CRT_OK;
+}
+
+int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
+{
+    if (!out) return CRT_E_INVALID;
+    *out = 0;
+    int d4 = 0, d2 = 0;
+    int rc = validate_desc(desc, &d4, &d2);
+    if (rc != CRT_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CRT_E_NODEVICE;
+    if (device < 0 || device >= ndev) return CRT_E_INVALID;
+    DeviceGuard guard(device);
+    if (!guard.ok) return CRT_E_HIP;
+
+    crt_scene* s = new (std::nothrow) crt_scene();
+    if (!s) return CRT_E_NOMEM;
+    memset(s, 0, sizeof *s);
+    s->device = device;
+    s->mode = CRT_TRAVERSE_AUTO;
+    const int n = desc->num_obj, nng = desc->num_non_grid_obj;
+
+    try {
+        /* object records (48 B) in final order */
+        std::vector<float4> objs((size_t)n * 3);
+        bool all_tri = true, accel_tri = true;
+        for (int i = 0; i < n; i++) {
+            const int t = desc->obj_type[i], r = desc->obj_ref[i];
+            const bool tri = (t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE);
+            float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (tri) memcpy(v, desc->tri_verts + (size_t)r * 9, sizeof v);
+            else { all_tri = false; if (i >= nng) accel_tri = false; }
+            float idf, tf, rf;
+            memcpy(&idf, &desc->obj_id[i], 4); memcpy(&tf, &t, 4); memcpy(&rf, &r, 4);
+            objs[(size_t)i*3 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+            objs[(size_t)i*3 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            objs[(size_t)i*3 + 2] = make_float4(v[8], idf, tf, rf);
+        }
+        s->tri_only = all_tri;
+        s->accel_tri_only = accel_tri;
+        if (desc->accel == CRT_ACCEL_BVH4 && !accel_tri && d4 > CRT_EXACT4_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
+        if (desc->accel == CRT_ACCEL_BVH && !accel_tri && d2 > CRT_EXACT2_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
+
+        std::vector<float4> n4;
+        if (desc->accel == CRT_ACCEL_BVH4) {
+            n4.resize((size_t)desc->num_nodes4 * 8);
+            for (int i = 0; i < desc->num_nodes4; i++) {
+                const crt_bvh4_node& nd = desc->nodes4[i];
+                float4* q = &n4[(size_t)i * 8];
+                for (int k = 0; k < 6; k++) q[k] = make_float4(nd.bbox[4*k], nd.bbox[4*k+1], nd.bbox[4*k+2], nd.bbox[4*k+3]);
+                unsigned w[4];
+                for (int c = 0; c < 4; c++)
+                    w[c] = nd.type[c] == -1 ? (unsigned)nd.child[c]
+                                            : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
+                float wf[4]; memcpy(wf, w, 16);
+                q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
+                int ax2 = nd.axis & 0x03;                          /* bvh4.h:308 */
+                float af; memcpy(&af, &ax2, 4);
+                q[7] = make_float4(af, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        std::vector<float4> n2;
+        if (desc->accel == CRT_ACCEL_BVH) {
+            n2.resize((size_t)desc->num_nodes2 * 2);
+            for (int i = 0; i < desc->num_nodes2; i++) {
+                const crt_bvh2_node& nd = desc->nodes2[i];
+                float lf, rf; memcpy(&lf, &nd.left, 4); memcpy(&rf, &nd.right, 4);
+                n2[(size_t)i*2]     = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], lf);
+                n2[(size_t)i*2 + 1] = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], rf);
+            }
+        }
+        std::vector<crt_shape> shapes;
+        if (desc->num_shapes > 0) shapes.assign(desc->shapes, desc->shapes + desc->num_shapes);
+        std::vector<int32_t> cs, ci;
+        if (desc->accel == CRT_ACCEL_GRID) {
+            cs.assign(desc->cell_start, desc->cell_start + desc->grid.num_cells + 1);
+            if (cs.back() > 0) ci.assign(desc->cell_items, desc->cell_items + cs.back());
+        }
+
+        if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK ||
+            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
+            (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK) {
+            free_scene(s);
+            return rc;
+        }
+    } catch (const std::bad_alloc&) {
+        free_scene(s);
+        return CRT_E_NOMEM;
+    }
+
+    int cus = 0;
+    if (!hip_ok(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute")) { free_scene(s); return CRT_E_HIP; }
+    s->num_cus = cus > 0 ? cus : 1;
+    s->ovf_threads = (unsigned)s->num_cus * 8u * CRT_BLOCK;           /* at most 8 resident 256-thread blocks per CU */
+    size_t ovf_bytes = (size_t)s->ovf_threads * CRT_OVF_DEPTH * sizeof(unsigned);
+    if (!hip_ok(hipMalloc((void**)&s->d_ovf_word, ovf_bytes), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->d_ovf_key, ovf_bytes), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->d_queue_head, 256), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset") ||
+        !hip_ok(hipEventCreate(&s->ev_start), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
+    if (!hip_ok(hipEventCreate(&s->ev_stop), "hipEventCreate")) { (void)hipEventDestroy(s->ev_start); free_scene(s); return CRT_E_HIP; }
+    s->ev_valid = true;
+
+    DevScene& dv = s->dev;
+    dv.nodes4 = (const float4*)s->d_nodes4;
+    dv.objs = (const float4*)s->d_objs;
+    dv.shapes = (const crt_shape*)s->d_shapes;
+    dv.nodes2 = (const float4*)s->d_nodes2;
+    dv.cell_start = (const int*)s->d_cell_start;
+    dv.cell_items = (const int*)s->d_cell_items;
+    dv.counters = s->d_counters;
+    dv.grid = desc->grid;
+    dv.num_obj = n; dv.nng = nng; dv.n_accel = n - nng; dv.accel = desc->accel;
+    *out = s;
+    return CRT_OK;
+}
+
+void crt_scene_destroy(crt_scene* s)
+{
+    if (!s) return;
+    DeviceGuard guard(s->device);
+    (void)hipDeviceSynchronize();
+    free_scene(s);
+}
+
+int crt_scene_set_traverse_mode(crt_scene* s, int mode)
+{
+    if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;
+    s->mode = mode;
+    return CRT_OK;
+}
+int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
+{
+    if (!s || !resolved) return CRT_E_INVALID;
+    *resolved = resolved_mode(s);
+    return CRT_OK;
+}
+
+int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
+{
+    if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
+    if (n == 0) return CRT_OK;
+    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;                        /* 32-bit queue head */
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st) : dispatch_closest<true, false>(s, la, st);
+    return s->count ? dispatch_closest<false, true>(s, la, st) : dispatch_closest<false, false>(s, la, st);
+}
+
+int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                         float* d_t_out, uint8_t* d_occluded_out, void* stream)
+{
+    if (!s || (n > 0 && (!d_rays || !d_light_dist))) return CRT_E_INVALID;
+    if (n == 0) return CRT_OK;
+    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    la.rays = d_rays; la.light_dist = d_light_dist; la.t_out = d_t_out; la.occ_out = d_occluded_out; la.n = (unsigned)n;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st) : dispatch_shadow<true, false>(s, la, st);
+    return s->count ? dispatch_shadow<false, true>(s, la, st) : dispatch_shadow<false, false>(s, la, st);
+}
+
+int crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits)
+{
+    if (!s || (n > 0 && (!rays || !hits))) return CRT_E_INVALID;
+    if (n == 0) return CRT_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    crt_ray* d_rays = 0; crt_hit* d_hits = 0;
+    int rc = CRT_OK;
+    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(crt_ray)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&d_hits, n * sizeof(crt_hit)), "hipMalloc")) rc = CRT_E_NOMEM;
+    if (rc == CRT_OK && !hip_ok(hipMemcpy(d_rays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice), "hipMemcpy H2D")) rc = CRT_E_HIP;
+    if (rc == CRT_OK) rc = crt_intersect_batch_dev(s, d_rays, n, d_hits, 0);
+    if (rc == CRT_OK && !hip_ok(hipMemcpy(hits, d_hits, n * sizeof(crt_hit), hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_hits) (void)hipFree(d_hits);
+    return rc;
+}
+
+int crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist, size_t n,
+                     float* t_out, uint8_t* occluded_out)
+{
+    if (!s || (n > 0 && (!rays || !light_dist))) return CRT_E_INVALID;
+    if (n == 0) return CRT_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    crt_ray* d_rays = 0; float* d_ld = 0; float* d_t = 0; uint8_t* d_occ = 0;
+    int rc = CRT_OK;
+    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(crt_ray)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&d_ld, n * sizeof(float)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&d_t, n * sizeof(float)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&d_occ, n), "hipMalloc")) rc = CRT_E_NOMEM;
+    if (rc == CRT_OK && (!hip_ok(hipMemcpy(d_rays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice), "hipMemcpy H2D") ||
+                         !hip_ok(hipMemcpy(d_ld, light_dist, n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy H2D"))) rc = CRT_E_HIP;
+    if (rc == CRT_OK) rc = crt_shadow_batch_dev(s, d_rays, d_ld, n, d_t, d_occ, 0);
+    if (rc == CRT_OK && t_out && !hip_ok(hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
+    if (rc == CRT_OK && occluded_out && !hip_ok(hipMemcpy(occluded_out, d_occ, n, hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
+    if (rc == CRT_OK && !t_out && !occluded_out && !hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) rc = CRT_E_HIP;
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_ld) (void)hipFree(d_ld);
+    if (d_t) (void)hipFree(d_t);
+    if (d_occ) (void)hipFree(d_occ);
+    return rc;
+}
+
+int crt_scene_enable_counters(crt_scene* s, int on)
+{
+    if (!s) return CRT_E_INVALID;
+    s->count = on != 0;
+    return CRT_OK;
+}
+int crt_scene_get_counters(crt_scene* s, crt_counters* out)
+{
+    if (!s || !out) return CRT_E_INVALID;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    unsigned long long h[4];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_visited = h[2]; out->prims_tested = h[3];
+    return CRT_OK;
+}
+int crt_scene_reset_counters(crt_scene* s)
+{
+    if (!s) return CRT_E_INVALID;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(s->d_counters, 0, 256));
+    return CRT_OK;
+}
+int crt_scene_last_kernel_ms(crt_scene* s, float* ms)
+{
+    if (!s || !ms) return CRT_E_INVALID;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    HIPCHK(hipEventSynchronize(s->ev_stop));
+    HIPCHK(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
+    return CRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,741 @@
+/*
+ * crt_kernels.h -- traversal kernels (gfx950, wave64).
+ *
+ * Execution model shared by every kernel here: a persistent grid (a few 256-thread
+ * workgroups per CU); each 64-lane wavefront pulls 64 consecutive rays at a time from an
+ * HBM-resident queue head (one agent-scope atomic per wave, broadcast with readfirstlane),
+ * one ray per lane, and loops until the queue is drained.  Per-lane traversal stacks live in
+ * LDS, laid out [entry][thread] so that a wave's access to one entry touches 64 consecutive
+ * dwords (bank = lane mod 32: conflict-free); entries beyond CRT_LDS_DEPTH spill to a per-scene
+ * HBM overflow area laid out the same way ([entry][global thread]).
+ */
+#pragma once
+#include "crt_device.h"
+
+#define CRT_BLOCK      256
+#define CRT_LDS_DEPTH  16
+#define CRT_OVF_DEPTH  32
+#define CRT_STACK_MAX  (CRT_LDS_DEPTH + CRT_OVF_DEPTH)
+#define CRT_EXACT4_DEPTH 16     /* QBVH levels the EXACT kernel's frame stack holds */
+#define CRT_EXACT2_DEPTH 64     /* binary-BVH levels the EXACT kernel's frame stack holds */
+
+struct LaunchArgs {
+    const crt_ray* rays;
+    const float* light_dist;      /* shadow only */
+    crt_hit* hits;                /* closest only */
+    float* t_out;                 /* shadow only, may be null */
+    uint8_t* occ_out;             /* shadow only, may be null */
+    unsigned n;
+    unsigned* queue_head;         /* zeroed before launch */
+    unsigned* ovf_word;           /* [CRT_OVF_DEPTH][grid threads] */
+    float* ovf_key;               /* [CRT_OVF_DEPTH][grid threads] */
+    unsigned grid_threads;
+};
+
+/* ---- per-lane stack ---------------------------------------------------------------- */
+struct LaneStack {
+    unsigned* lds_word;           /* &s_word[0][tid] */
+    float* lds_key;               /* &s_key[0][tid]  */
+    unsigned* ovf_word;           /* &ovf_word[0][gtid] */
+    float* ovf_key;
+    unsigned ovf_stride;
+    int sp;
+    CRT_DEV void push(unsigned w, float key)
+    {
+        if (sp < CRT_LDS_DEPTH) { lds_word[sp * CRT_BLOCK] = w; lds_key[sp * CRT_BLOCK] = key; }
+        else if (sp < CRT_STACK_MAX) {
+            size_t o = (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride;
+            ovf_word[o] = w; ovf_key[o] = key;
+        }
+        /* deeper than CRT_STACK_MAX cannot happen: crt_scene_create rejects such trees */
+        sp++;
+    }
+    CRT_DEV void pop(unsigned* w, float* key)
+    {
+        sp--;
+        if (sp < CRT_LDS_DEPTH) { *w = lds_word[sp * CRT_BLOCK]; *key = lds_key[sp * CRT_BLOCK]; }
+        else {
+            size_t o = (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride;
+            *w = ovf_word[o]; *key = ovf_key[o];
+        }
+    }
+};
+
+CRT_DEV DRay load_ray(const crt_ray* rays, unsigned i)
+{
+    const float2* p = reinterpret_cast<const float2*>(rays + i);    /* 24-B records, 8-B aligned */
+    float2 a = p[0], b = p[1], c = p[2];
+    DRay r; r.ox = a.x; r.oy = a.y; r.oz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
+    return r;
+}
+CRT_DEV void store_hit(crt_hit* hits, unsigned i, float t, const DHit& h)
+{
+    crt_hit o;
+    o.t = t;
+    if (t < CRT_TMAX) { o.obj = h.obj; o.part = h.part; o.beta = h.beta; o.gamma = h.gamma; }
+    else { o.obj = -1; o.part = -1; o.beta = 0.0f; o.gamma = 0.0f; }
+    hits[i] = o;
+}
+
+/* Wave-level fetch of the next 64 rays. */
+CRT_DEV unsigned next_batch(unsigned* queue_head)
+{
+    unsigned base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(queue_head, 64u);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+}
+
+template <bool COUNT>
+CRT_DEV void flush_counters(const DevScene& sc, unsigned rays, unsigned nodes, unsigned prims, bool shadow)
+{
+    if (COUNT) {
+        atomicAdd(&sc.counters[shadow ? 1 : 0], (unsigned long long)rays);
+        atomicAdd(&sc.counters[2], (unsigned long long)nodes);
+        atomicAdd(&sc.counters[3], (unsigned long long)prims);
+    }
+}
+
+/* rayIntersectAABB4 (accelerator/bvh4.h:23-97) for child c of a node held in registers.
+ * SSE max/min semantics: a > b ? a : b (second operand when unordered).  Returns the t the
+ * reference stores (entry t0 if t0 > eps, else exit t1, TMAX on miss); *lt = (t0 < eps). */
+CRT_DEV float box4(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                   const DRay& r, float ia, float ib, float ic, bool sx, bool sy, bool sz, bool* lt)
+{
+    float tx_min = ((sx ? mnx : mxx) - r.ox) * ia, tx_max = ((sx ? mxx : mnx) - r.ox) * ia;
+    float ty_min = ((sy ? mny : mxy) - r.oy) * ib, ty_max = ((sy ? mxy : mny) - r.oy) * ib;
+    float tz_min = ((sz ? mnz : mxz) - r.oz) * ic, tz_max = ((sz ? mxz : mnz) - r.oz) * ic;
+    float m0 = tx_min > ty_min ? tx_min : ty_min;
+    float t0 = m0 > tz_min ? m0 : tz_min;
+    float m1 = tx_max < ty_max ? tx_max : ty_max;
+    float t1 = m1 < tz_max ? m1 : tz_max;
+    bool hit = (t0 < t1) && (t1 > CRT_K_EPSILON);
+    *lt = (t0 < CRT_K_EPSILON);
+    float t = (t0 > CRT_K_EPSILON) ? t0 : t1;
+    return hit ? t : CRT_TMAX;
+}
+
+/* Linear pass over objects[first, last) -- the non-grid loops of intersectTest
+ * (intersect.h:387-395,:403-411) and the NONE branch (:416-432): strict `<`. */
+template <bool TRI_ONLY, bool COUNT>
+CRT_DEV void linear_closest(const DevScene& sc, int first, int last, const DRay& ray, float* best_t, DHit* best, unsigned* prims)
+{
+    for (int i = first; i < last; i++) {
+        DHit h;
+        float t = dev_object<TRI_ONLY>(sc, i, ray, false, &h);
+        if (COUNT) (*prims)++;
+        if (t < *best_t) { *best_t = t; *best = h; }
+    }
+}
+/* shadow flavour (intersect.h:460-467,:476-483,:490-497): t = last tested, return on t < bound */
+template <bool TRI_ONLY, bool COUNT>
+CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay& ray, float bound, float t, unsigned* prims)
+{
+    for (int i = first; i < last; i++) {
+        DHit h;
+        t = dev_object<TRI_ONLY>(sc, i, ray, true, &h);
+        if (COUNT) (*prims)++;
+        if (t < bound) return t;
+    }
+    return t;
+}
+
+/* =====================================================================================
+ * QBVH closest hit, best-t pruned, reference child order.
+ * BVH4IntersectTest (accelerator/bvh4.h:299-389) + the BVH4 branch of intersectTest
+ * (intersect.h:397-412).  Children are visited in the reference's order and with its test
+ *     box_t < min_t || (less_than && box_t < TMAX)                            (bvh4.h:358)
+ * where min_t is the ray's nearest hit so far instead of the per-node local of bvh4.h:354;
+ * the test is applied when a child is pushed and again when it is popped, which is the same
+ * as applying it when the recursive version reaches the child.
+ * ===================================================================================== */
+template <bool TRI_ONLY, bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchArgs la)
+{
+    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    LaneStack st;
+    st.lds_word = &s_word[0][threadIdx.x];
+    st.lds_key = &s_key[0][threadIdx.x];
+    st.ovf_word = la.ovf_word + gtid;
+    st.ovf_key = la.ovf_key + gtid;
+    st.ovf_stride = la.grid_threads;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;   /* bvh4.h:26-28 */
+            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f; /* bvh4.h:43,:54,:65 */
+            const bool px = ray.dx > 0.0f;                                             /* bvh4.h:312 (axis0 = axis1 = 0) */
+            float best_t = CRT_TMAX;
+            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+            st.sp = 0;
+            bool alive = sc.n_accel > 0;
+            unsigned cur = 0;                              /* root */
+            while (alive) {
+                if (!(cur & CRT_LEAF_BIT)) {
+                    const float4* nd = sc.nodes4 + (size_t)cur * 8;
+                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    if (COUNT) c_nodes++;
+                    bool l0, l1, l2, l3;
+                    const float b0 = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &l0);
+                    const float b1 = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &l1);
+                    const float b2 = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &l2);
+                    const float b3 = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &l3);
+                    /* key: -inf for "origin inside/behind the box" children (always visited when hit) */
+                    const float ninf = -__builtin_huge_valf();
+                    const float k0 = (l0 && b0 < CRT_TMAX) ? ninf : b0;
+                    const float k1 = (l1 && b1 < CRT_TMAX) ? ninf : b1;
+                    const float k2 = (l2 && b2 < CRT_TMAX) ? ninf : b2;
+                    const float k3 = (l3 && b3 < CRT_TMAX) ? ninf : b3;
+                    const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
+                    const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
+                    const int ax2 = __float_as_int(q7.x);
+                    const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
+                    const bool p2 = dax > 0.0f;                                       /* bvh4.h:323,:334 */
+                    /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
+                    const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
+                    const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
+                    const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
+                    const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
+                    if (s3k < best_t) st.push(s3w, s3k);
+                    if (s2k < best_t) st.push(s2w, s2k);
+                    if (s1k < best_t) st.push(s1w, s1k);
+                    if (s0k < best_t) { cur = s0w; continue; }
+                } else {
+                    const int count = (int)((cur >> 28) & 7u);
+                    const int first = (int)(cur & 0x0FFFFFFFu);
+                    for (int j = 0; j < count; j++) {                                 /* bvh4.h:374-383 */
+                        DHit h;
+                        const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
+                        if (COUNT) c_prims++;
+                        if (t < best_t) { best_t = t; best = h; }
+                    }
+                }
+                alive = false;
+                while (st.sp > 0) {
+                    unsigned w; float key;
+                    st.pop(&w, &key);
+                    if (key < best_t) { cur = w; alive = true; break; }
+                }
+            }
+            linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+            store_hit(la.hits, ri, best_t, best);
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, false);
+}
+
+/* =====================================================================================
+ * QBVH any hit: BVH4ShadowIntersectTest (bvh4.h:392-478) + BVH4 branch of shadowIntersectTest
+ * (intersect.h:470-485).  Same order; bound is the constant light_dist; first t < light_dist
+ * in traversal order ends the walk (so the reported t is the reference's, quirk (5)).
+ * ===================================================================================== */
+template <bool TRI_ONLY, bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchArgs la)
+{
+    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    LaneStack st;
+    st.lds_word = &s_word[0][threadIdx.x];
+    st.lds_key = &s_key[0][threadIdx.x];
+    st.ovf_word = la.ovf_word + gtid;
+    st.ovf_key = la.ovf_key + gtid;
+    st.ovf_stride = la.grid_threads;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            const float ld = la.light_dist[ri];
+            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;
+            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
+            const bool px = ray.dx > 0.0f;
+            float result = CRT_TMAX;
+            st.sp = 0;
+            bool alive = sc.n_accel > 0;
+            unsigned cur = 0;
+            while (alive) {
+                if (!(cur & CRT_LEAF_BIT)) {
+                    const float4* nd = sc.nodes4 + (size_t)cur * 8;
+                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    if (COUNT) c_nodes++;
+                    bool l0, l1, l2, l3;
+                    const float b0 = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &l0);
+                    const float b1 = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &l1);
+                    const float b2 = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &l2);
+                    const float b3 = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &l3);
+                    const bool v0 = b0 < ld || (l0 && b0 < CRT_TMAX);                 /* bvh4.h:450 */
+                    const bool v1 = b1 < ld || (l1 && b1 < CRT_TMAX);
+                    const bool v2 = b2 < ld || (l2 && b2 < CRT_TMAX);
+                    const bool v3 = b3 < ld || (l3 && b3 < CRT_TMAX);
+                    const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
+                    const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
+                    const int ax2 = __float_as_int(q7.x);
+                    const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
+                    const bool p2 = dax > 0.0f;
+                    const bool vC = p2 ? v2 : v3, vD = p2 ? v3 : v2;
+                    const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
+                    const bool s0v = px ? v0 : vC, s1v = px ? v1 : vD, s2v = px ? vC : v1, s3v = px ? vD : v0;
+                    const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
+                    if (s3v) st.push(s3w, 0.0f);
+                    if (s2v) st.push(s2w, 0.0f);
+                    if (s1v) st.push(s1w, 0.0f);
+                    if (s0v) { cur = s0w; continue; }
+                } else {
+                    const int count = (int)((cur >> 28) & 7u);
+                    const int first = (int)(cur & 0x0FFFFFFFu);
+                    bool found = false;
+                    for (int j = 0; j < count; j++) {                                 /* bvh4.h:464-472 */
+                        DHit h;
+                        const float t = dev_object<TRI_ONLY>(sc, first + j, ray, true, &h);
+                        if (COUNT) c_prims++;
+                        if (t < ld) { result = t; found = true; break; }
+                    }
+                    if (found) break;
+                }
+                if (st.sp > 0) { float key; st.pop(&cur, &key); }
+                else alive = false;
+            }
+            if (result >= ld)                                                          /* intersect.h:474 */
+                result = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, result, &c_prims);
+            if (la.t_out) la.t_out[ri] = result;
+            if (la.occ_out) la.occ_out[ri] = (result < ld - CRT_K_EPSILON) ? 1 : 0;   /* trace.h:348 */
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, true);
+}
+
+/* =====================================================================================
+ * No accelerator: the NONE branches of intersectTest / shadowIntersectTest
+ * (intersect.h:413-433, :486-498).
+ * ===================================================================================== */
+template <bool TRI_ONLY, bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void k_none_closest(DevScene sc, LaunchArgs la)
+{
+    const unsigned lane = threadIdx.x & 63;
+    unsigned c_rays = 0, c_prims = 0;
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            float best_t = CRT_TMAX;
+            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+            linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.num_obj, ray, &best_t, &best, &c_prims);
+            store_hit(la.hits, ri, best_t, best);
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, 0, c_prims, false);
+}
+template <bool TRI_ONLY, bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchArgs la)
+{
+    const unsigned lane = threadIdx.x & 63;
+    unsigned c_rays = 0, c_prims = 0;
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            const float ld = la.light_dist[ri];
+            const float t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.num_obj, ray, ld, CRT_TMAX, &c_prims);
+            if (la.t_out) la.t_out[ri] = t;
+            if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, 0, c_prims, true);
+}
+
+/* =====================================================================================
+ * Binary BVH, best-t pruned.  BVHIntersectTest (intersect.h:310-342): left then right, the
+ * right subtree wins equal t (t1 < t2 ? left : right) -> a later hit replaces on `<=`.
+ * A child box is skipped when the reference would skip it (rayIntersectAABB == TMAX) or when
+ * its entry t0 (> eps) lies strictly beyond the nearest hit.  SHADOW = true gives
+ * BVHShadowIntersectTest (intersect.h:344-362): min t over the tree, light_dist unused.
+ * ===================================================================================== */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+__global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
+{
+    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    LaneStack st;
+    st.lds_word = &s_word[0][threadIdx.x];
+    st.lds_key = &s_key[0][threadIdx.x];
+    st.ovf_word = la.ovf_word + gtid;
+    st.ovf_key = la.ovf_key + gtid;
+    st.ovf_stride = la.grid_threads;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+    const float ninf = -__builtin_huge_valf();
+
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            float best_t = CRT_TMAX;
+            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+            st.sp = 0;
+            bool alive = false;
+            unsigned cur = 0;
+            if (sc.n_accel > 0) {                                   /* root box, intersect.h:381,:454 */
+                const float4 a = sc.nodes2[0], b = sc.nodes2[1];
+                float bmin[3] = { a.x, a.y, a.z }, bmax[3] = { b.x, b.y, b.z }, t0;
+                if (COUNT) c_nodes++;
+                alive = dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX;
+            }
+            while (alive) {
+                const float4 a = sc.nodes2[(size_t)cur * 2], b = sc.nodes2[(size_t)cur * 2 + 1];
+                const int left = __float_as_int(a.w), right = __float_as_int(b.w);
+                if (left < 0) {
+                    DHit h;
+                    const float t = dev_object<TRI_ONLY>(sc, right, ray, SHADOW, &h);
+                    if (COUNT) c_prims++;
+                    if (SHADOW) { if (t < best_t) best_t = t; }
+                    else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }
+                } else {
+                    const float4 la0 = sc.nodes2[(size_t)left * 2], la1 = sc.nodes2[(size_t)left * 2 + 1];
+                    const float4 ra0 = sc.nodes2[(size_t)right * 2], ra1 = sc.nodes2[(size_t)right * 2 + 1];
+                    if (COUNT) c_nodes += 2;
+                    float lmin[3] = { la0.x, la0.y, la0.z }, lmax[3] = { la1.x, la1.y, la1.z };
+                    float rmn[3] = { ra0.x, ra0.y, ra0.z }, rmx[3] = { ra1.x, ra1.y, ra1.z };
+                    float lt0, rt0;
+                    const float lbt = dev_ray_aabb(lmin, lmax, ray, &lt0);
+                    const float rbt = dev_ray_aabb(rmn, rmx, ray, &rt0);
+                    const float lkey = lt0 > CRT_K_EPSILON ? lt0 : ninf;
+                    const float rkey = rt0 > CRT_K_EPSILON ? rt0 : ninf;
+                    const bool lv = lbt < CRT_TMAX && !(lkey > best_t);
+                    const bool rv = rbt < CRT_TMAX && !(rkey > best_t);
+                    if (rv) st.push((unsigned)right, rkey);
+                    if (lv) { cur = (unsigned)left; continue; }
+                }
+                alive = false;
+                while (st.sp > 0) {
+                    unsigned w; float key;
+                    st.pop(&w, &key);
+                    if (!(key > best_t)) { cur = w; alive = true; break; }
+                }
+            }
+            if (!SHADOW) {
+                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                store_hit(la.hits, ri, best_t, best);
+            } else {
+                const float ld = la.light_dist[ri];
+                float t = best_t;
+                if (t >= ld) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, t, &c_prims);   /* intersect.h:458-468 */
+                if (la.t_out) la.t_out[ri] = t;
+                if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+            }
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
+}
+
+/* =====================================================================================
+ * Uniform grid 3D-DDA: gridIntersectTest (intersect.h:61-194) / gridShadowIntersectTest
+ * (:196-308).  Divisions, the `min(...) == obj_t` accept test and the stepping comparisons are
+ * kept as written, so rays with a zero direction component follow the reference's inf/NaN flow.
+ * ===================================================================================== */
+struct GridWalk {
+    int ix, iy, iz, sx, sy, sz, ex, ey, ez;
+    float tx, ty, tz, dtx, dty, dtz;
+    bool hits;
+};
+CRT_DEV void grid_setup(const DevScene& sc, const DRay& ray, GridWalk* w)
+{
+    const crt_grid& g = sc.grid;
+    w->hits = false; w->ix = w->iy = w->iz = 0;
+    float px = ray.ox, py = ray.oy, pz = ray.oz;
+    const bool inside = !(px < g.bmin[0] || px > g.bmax[0]) && !(py < g.bmin[1] || py > g.bmax[1]) &&
+                        !(pz < g.bmin[2] || pz > g.bmax[2]);                          /* aabb.cpp:171-181 */
+    if (inside) w->hits = true;
+    else {
+        float t0e;
+        const float t0 = dev_ray_aabb(g.bmin, g.bmax, ray, &t0e);
+        if (t0 < CRT_TMAX) { px = ray.ox + ray.dx * t0; py = ray.oy + ray.dy * t0; pz = ray.oz + ray.dz * t0; w->hits = true; }
+    }
+    if (!w->hits) return;
+    w->ix = (int)rclamp((px - g.bmin[0]) / g.wx * g.nx, 0.0f, (float)g.nx - 1);
+    w->iy = (int)rclamp((py - g.bmin[1]) / g.wy * g.ny, 0.0f, (float)g.ny - 1);
+    w->iz = (int)rclamp((pz - g.bmin[2]) / g.wz * g.nz, 0.0f, (float)g.nz - 1);
+    const bool gx = ray.dx > 0, gy = ray.dy > 0, gz = ray.dz > 0;
+    const float tx_min = ((gx ? g.bmin[0] : g.bmax[0]) - ray.ox) / ray.dx;
+    const float ty_min = ((gy ? g.bmin[1] : g.bmax[1]) - ray.oy) / ray.dy;
+    const float tz_min = ((gz ? g.bmin[2] : g.bmax[2]) - ray.oz) / ray.dz;
+    const float tx_max = ((gx ? g.bmax[0] : g.bmin[0]) - ray.ox) / ray.dx;
+    const float ty_max = ((gy ? g.bmax[1] : g.bmin[1]) - ray.oy) / ray.dy;
+    const float tz_max = ((gz ? g.bmax[2] : g.bmin[2]) - ray.oz) / ray.dz;
+    w->dtx = (tx_max - tx_min) / g.nx;
+    w->dty = (ty_max - ty_min) / g.ny;
+    w->dtz = (tz_max - tz_min) / g.nz;
+    w->sx = gx ? 1 : -1; w->sy = gy ? 1 : -1; w->sz = gz ? 1 : -1;
+    w->ex = gx ? g.nx : -1; w->ey = gy ? g.ny : -1; w->ez = gz ? g.nz : -1;
+    const int tix = gx ? w->ix : g.nx - w->ix - 1;
+    const int tiy = gy ? w->iy : g.ny - w->iy - 1;
+    const int tiz = gz ? w->iz : g.nz - w->iz - 1;
+    w->tx = tx_min + w->dtx * (tix + 1);
+    w->ty = ty_min + w->dty * (tiy + 1);
+    w->tz = tz_min + w->dtz * (tiz + 1);
+}
+CRT_DEV void grid_step(GridWalk* w)
+{
+    if (w->tx < w->ty && w->tx < w->tz) { w->tx += w->dtx; w->ix += w->sx; }
+    else if (w->ty < w->tz) { w->ty += w->dty; w->iy += w->sy; }
+    else { w->tz += w->dtz; w->iz += w->sz; }
+}
+
+template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+__global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
+{
+    const unsigned lane = threadIdx.x & 63;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            const float ld = SHADOW ? la.light_dist[ri] : 0.0f;
+            const float bound = ld - CRT_K_EPSILON;                                    /* intersect.h:276 */
+            GridWalk w;
+            grid_setup(sc, ray, &w);
+            float t = CRT_TMAX;
+            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+            bool done = false;
+            if (w.hits) {
+                while (w.ix != w.ex && w.iy != w.ey && w.iz != w.ez) {
+                    const int cell = w.iy * sc.grid.nz * sc.grid.nx + w.iz * sc.grid.nx + w.ix;
+                    const int cb = sc.cell_start[cell], ce = sc.cell_start[cell + 1];
+                    if (COUNT) c_nodes++;
+                    if (!SHADOW) {
+                        float obj_t = CRT_TMAX;
+                        DHit obj_h = best;
+                        for (int k = cb; k < ce; k++) {
+                            DHit h;
+                            const float tt = dev_object<TRI_ONLY>(sc, sc.cell_items[k], ray, false, &h);
+                            if (COUNT) c_prims++;
+                            if (tt < obj_t) { obj_t = tt; obj_h = h; }
+                        }
+                        if (rmin(obj_t, rmin(w.tx, rmin(w.ty, w.tz))) == obj_t) {       /* intersect.h:152 */
+                            if (obj_t < CRT_TMAX) { best = obj_h; t = obj_t; break; }
+                        }
+                    } else {
+                        for (int k = cb; k < ce; k++) {
+                            DHit h;
+                            const float tt = dev_object<TRI_ONLY>(sc, sc.cell_items[k], ray, true, &h);
+                            if (COUNT) c_prims++;
+                            if (tt < bound) { t = tt; done = true; break; }
+                        }
+                        if (done) break;
+                    }
+                    grid_step(&w);
+                }
+            }
+            if (!SHADOW) {
+                float min_t = CRT_TMAX;
+                DHit mh = best;
+                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &min_t, &mh, &c_prims);   /* intersect.h:177-192 */
+                if (min_t < t) { best = mh; t = min_t; }
+                store_hit(la.hits, ri, t, best);
+            } else {
+                if (!done) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, bound, CRT_TMAX, &c_prims);  /* :298-307 */
+                if (la.t_out) la.t_out[ri] = t;
+                if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+            }
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
+}
+
+/* =====================================================================================
+ * EXACT mode: the reference's own control flow, for scenes whose boxes do not bound their
+ * objects (rotated / scaled instances).  Recursion is unrolled onto a per-lane frame stack in
+ * private memory; these kernels serve small analytic scenes, not the throughput path.
+ * ===================================================================================== */
+struct Frame4 { unsigned node; int k; float local_t; DHit hit; };
+
+/* BVH4IntersectTest with min_t local to each node visit (bvh4.h:354-388) */
+template <bool TRI_ONLY, bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest_exact(DevScene sc, LaunchArgs la)
+{
+    const unsigned lane = threadIdx.x & 63;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;
+            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
+            const bool px = ray.dx > 0.0f;
+            Frame4 fr[CRT_EXACT4_DEPTH];
+            int depth = -1;
+            float ret_t = CRT_TMAX;
+            DHit ret_h; ret_h.obj = -1; ret_h.part = -1; ret_h.beta = 0.0f; ret_h.gamma = 0.0f;
+            bool returning = false;
+            if (sc.n_accel > 0) { depth = 0; fr[0].node = 0; fr[0].k = 0; fr[0].local_t = CRT_TMAX; fr[0].hit = ret_h; }
+            while (depth >= 0) {
+                Frame4 f = fr[depth];
+                if (returning) {                                                       /* bvh4.h:366-370 */
+                    if (ret_t < f.local_t) { f.local_t = ret_t; f.hit = ret_h; }
+                    returning = false;
+                } else if (COUNT && f.k == 0) c_nodes++;
+                const float4* nd = sc.nodes4 + (size_t)f.node * 8;
+                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                float bt[4]; bool lt[4]; unsigned cw[4];
+                bt[0] = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &lt[0]);
+                bt[1] = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &lt[1]);
+                bt[2] = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &lt[2]);
+                bt[3] = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &lt[3]);
+                cw[0] = __float_as_uint(q6.x); cw[1] = __float_as_uint(q6.y); cw[2] = __float_as_uint(q6.z); cw[3] = __float_as_uint(q6.w);
+                const int ax2 = __float_as_int(q7.x);
+                const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
+                const bool p2 = dax > 0.0f;
+                int order[4];
+                if (px) { order[0] = 0; order[1] = 1; order[2] = p2 ? 2 : 3; order[3] = p2 ? 3 : 2; }
+                else    { order[0] = p2 ? 2 : 3; order[1] = p2 ? 3 : 2; order[2] = 1; order[3] = 0; }
+                bool descended = false;
+                while (f.k < 4) {
+                    const int idx = order[f.k];
+                    f.k++;
+                    if (bt[idx] < f.local_t || (lt[idx] && bt[idx] < CRT_TMAX)) {      /* bvh4.h:358 */
+                        const unsigned w = cw[idx];
+                        if (!(w & CRT_LEAF_BIT)) {
+                            if (depth + 1 < CRT_EXACT4_DEPTH) {
+                                fr[depth] = f;
+                                depth++;
+                                fr[depth].node = w; fr[depth].k = 0; fr[depth].local_t = CRT_TMAX; fr[depth].hit = ret_h;
+                                descended = true;
+                                break;
+                            }
+                        } else {
+                            const int count = (int)((w >> 28) & 7u), first = (int)(w & 0x0FFFFFFFu);
+                            for (int j = 0; j < count; j++) {
+                                DHit h;
+                                const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
+                                if (COUNT) c_prims++;
+                                if (t < f.local_t) { f.local_t = t; f.hit = h; }
+                            }
+                        }
+                    }
+                }
+                if (!descended) { ret_t = f.local_t; ret_h = f.hit; returning = true; depth--; }
+            }
+            float best_t = ret_t;
+            DHit best = ret_h;
+            linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+            store_hit(la.hits, ri, best_t, best);
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, false);
+}
+
+struct Frame2 { int node; int state; float t1; DHit h1; };
+
+/* BVHIntersectTest / BVHShadowIntersectTest as written (intersect.h:310-362): every
+ * box-overlapped subtree is walked, the pick is `t1 < t2 ? left : right`. */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+__global__ __launch_bounds__(CRT_BLOCK) void k_bvh2_exact(DevScene sc, LaunchArgs la)
+{
+    const unsigned lane = threadIdx.x & 63;
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+    for (;;) {
+        const unsigned base = next_batch(la.queue_head);
+        if (base >= la.n) break;
+        const unsigned ri = base + lane;
+        if (ri < la.n) {
+            const DRay ray = load_ray(la.rays, ri);
+            Frame2 fr[CRT_EXACT2_DEPTH];
+            int depth = -1;
+            float ret_t = CRT_TMAX;
+            DHit none; none.obj = -1; none.part = -1; none.beta = 0.0f; none.gamma = 0.0f;
+            DHit ret_h = none;
+            if (sc.n_accel > 0) {
+                const float4 a = sc.nodes2[0], b = sc.nodes2[1];
+                float bmin[3] = { a.x, a.y, a.z }, bmax[3] = { b.x, b.y, b.z }, t0;
+                if (COUNT) c_nodes++;
+                if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX) { depth = 0; fr[0].node = 0; fr[0].state = 0; fr[0].t1 = CRT_TMAX; fr[0].h1 = none; }
+            }
+            while (depth >= 0) {
+                Frame2 f = fr[depth];
+                const float4 a = sc.nodes2[(size_t)f.node * 2], b = sc.nodes2[(size_t)f.node * 2 + 1];
+                const int left = __float_as_int(a.w), right = __float_as_int(b.w);
+                if (left < 0) {
+                    DHit h;
+                    ret_t = dev_object<TRI_ONLY>(sc, right, ray, SHADOW, &h);
+                    ret_h = h;
+                    if (COUNT) c_prims++;
+                    depth--;
+                    continue;
+                }
+                if (f.state == 0) {                              /* left child */
+                    const float4 c0 = sc.nodes2[(size_t)left * 2], c1 = sc.nodes2[(size_t)left * 2 + 1];
+                    float bmin[3] = { c0.x, c0.y, c0.z }, bmax[3] = { c1.x, c1.y, c1.z }, t0;
+                    if (COUNT) c_nodes++;
+                    f.state = 1;
+                    if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX && depth + 1 < CRT_EXACT2_DEPTH) {
+                        fr[depth] = f;
+                        depth++;
+                        fr[depth].node = left; fr[depth].state = 0; fr[depth].t1 = CRT_TMAX; fr[depth].h1 = none;
+                        continue;
+                    }
+                    ret_t = CRT_TMAX; ret_h = none;              /* t1 stays TMAX */
+                }
+                if (f.state == 1) {                              /* back from (or skipped) left: record t1, go right */
+                    f.t1 = ret_t; f.h1 = ret_h;
+                    const float4 c0 = sc.nodes2[(size_t)right * 2], c1 = sc.nodes2[(size_t)right * 2 + 1];
+                    float bmin[3] = { c0.x, c0.y, c0.z }, bmax[3] = { c1.x, c1.y, c1.z }, t0;
+                    if (COUNT) c_nodes++;
+                    f.state = 2;
+                    if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX && depth + 1 < CRT_EXACT2_DEPTH) {
+                        fr[depth] = f;
+                        depth++;
+                        fr[depth].node = right; fr[depth].state = 0; fr[depth].t1 = CRT_TMAX; fr[depth].h1 = none;
+                        continue;
+                    }
+                    ret_t = CRT_TMAX; ret_h = none;              /* t2 stays TMAX */
+                }
+                /* state 2: ret_* is t2 */
+                if (f.t1 < ret_t) { ret_t = f.t1; ret_h = f.h1; }                      /* intersect.h:327-338,:360 */
+                depth--;
+            }
+            if (!SHADOW) {
+                float best_t = ret_t;
+                DHit best = ret_h;
+                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                store_hit(la.hits, ri, best_t, best);
+            } else {
+                const float ld = la.light_dist[ri];
+                float t = ret_t;
+                if (t >= ld) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, t, &c_prims);
+                if (la.t_out) la.t_out[ri] = t;
+                if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+            }
+            if (COUNT) c_rays++;
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
+}

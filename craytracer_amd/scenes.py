@@ -1,0 +1,409 @@
+"""Synthetic scenes and ray sets for the traversal path (numpy, host side).
+
+The reference ships no meshes (Buddha / San Miguel / Car / Coffee are absent) and
+nothing can be fetched, so the large configurations run on procedural stand-ins of the stated
+triangle counts.  Scene S1 takes its geometry verbatim from /root/reference/cornell_box.txt:70-246
+(9 rectangles + 20 triangles; data, not code).
+"""
+import math
+
+import numpy as np
+
+from . import api
+
+F32 = np.float32
+
+# ---------------------------------------------------------------------------------------
+# S1: cornell box (cornell_box.txt:70-246).  RECT rows: point, width, height.  TRI rows: v0 v1 v2.
+# Floor and ceiling are listed twice in the file (:82-92 vs :112-122) -> exact-t tie class T1.
+CORNELL_RECTS = [
+    [213.0, 548.0, -227.0, 130.0, 0.0, 0.0, 0.0, 0.0, -105.0],
+    [343.0, 548.0, -227.0, -130.0, 0.0, 0.0, 0.0, 0.0, -105.0],
+    [0.0, 0.0, 0.0, 552.8, 0.0, 0.0, 0.0, 0.0, -559.2],
+    [0.0, 548.8, 0.0, 0.0, 0.0, -559.2, 556.0, 0.0, 0.0],
+    [0.0, 0.0, -559.2, 553.6, 0.0, 0.0, 0.0, 548.8, 0.0],
+    [0.0, 0.0, 0.0, 0.0, 0.0, -559.2, 0.0, 548.8, 0.0],
+    [552.8, 0.0, 0.0, 0.0, 548.8, 0.0, 0.0, 0.0, -559.2],
+    [0.0, 0.0, 0.0, 552.8, 0.0, 0.0, 0.0, 0.0, -559.2],
+    [0.0, 548.8, 0.0, 0.0, 0.0, -559.2, 556.0, 0.0, 0.0],
+]
+CORNELL_TRIS = [
+    [423.0, 330.0, -247.0, 265.0, 330.0, -296.0, 314.0, 330.0, -456.0],
+    [423.0, 330.0, -247.0, 314.0, 330.0, -456.0, 472.0, 330.0, -406.0],
+    [423.0, 0.0, -247.0, 423.0, 330.0, -247.0, 472.0, 330.0, -406.0],
+    [423.0, 0.0, -247.0, 472.0, 330.0, -406.0, 472.0, 0.0, -406.0],
+    [472.0, 0.0, -406.0, 472.0, 330.0, -406.0, 314.0, 330.0, -456.0],
+    [472.0, 0.0, -406.0, 314.0, 330.0, -456.0, 314.0, 0.0, -456.0],
+    [314.0, 0.0, -456.0, 314.0, 330.0, -456.0, 265.0, 330.0, -296.0],
+    [314.0, 0.0, -456.0, 265.0, 330.0, -296.0, 265.0, 0.0, -296.0],
+    [265.0, 0.0, -296.0, 265.0, 330.0, -296.0, 423.0, 330.0, -247.0],
+    [265.0, 0.0, -296.0, 423.0, 330.0, -247.0, 423.0, 0.0, -247.0],
+    [130.0, 165.0, -65.0, 82.0, 165.0, -225.0, 240.0, 165.0, -272.0],
+    [130.0, 165.0, -65.0, 240.0, 165.0, -272.0, 290.0, 165.0, -114.0],
+    [290.0, 0.0, -114.0, 290.0, 165.0, -114.0, 240.0, 165.0, -272.0],
+    [290.0, 0.0, -114.0, 240.0, 165.0, -272.0, 240.0, 0.0, -272.0],
+    [130.0, 0.0, -65.0, 130.0, 165.0, -65.0, 290.0, 165.0, -114.0],
+    [130.0, 0.0, -65.0, 290.0, 165.0, -114.0, 290.0, 0.0, -114.0],
+    [82.0, 0.0, -225.0, 82.0, 165.0, -225.0, 130.0, 165.0, -65.0],
+    [82.0, 0.0, -225.0, 130.0, 165.0, -65.0, 130.0, 0.0, -65.0],
+    [240.0, 0.0, -272.0, 240.0, 165.0, -272.0, 82.0, 165.0, -225.0],
+    [240.0, 0.0, -272.0, 82.0, 165.0, -225.0, 82.0, 0.0, -225.0],
+]
+CORNELL_CAMERA = ((278.0, 273.0, 800.0), (278.0, 273.0, 0.0))     # cornell_box.txt:2-3
+
+
+def _normalize32(v):
+    """vec3_normalize (util/vec.h:206-215) in float32."""
+    v = np.asarray(v, F32)
+    length = F32(np.sqrt(F32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]))
+    if length == 0:
+        return np.zeros(3, F32)
+    return (v * F32(F32(1.0) / length)).astype(F32)
+
+
+def _cross32(a, b):
+    a = np.asarray(a, F32)
+    b = np.asarray(b, F32)
+    return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F32)
+
+
+class ShapeList:
+    """Accumulates analytic shapes + objects in insertion order."""
+
+    def __init__(self):
+        self.shapes = []
+        self.obj_type = []
+        self.obj_ref = []
+        self.tris = []
+
+    def _shape(self, type_, p=(), inner=-1, first_part=0, num_parts=0, inv_xform=None):
+        rec = np.zeros(1, api.SHAPE_DTYPE)[0]
+        rec["type"] = type_
+        rec["inner"] = inner
+        rec["first_part"] = first_part
+        rec["num_parts"] = num_parts
+        pp = np.zeros(12, F32)
+        pp[:len(p)] = np.asarray(p, F32)
+        rec["p"] = pp
+        rec["inv_xform"] = np.eye(4, dtype=F32).reshape(16) if inv_xform is None else np.asarray(inv_xform, F32).reshape(16)
+        self.shapes.append(rec)
+        return len(self.shapes) - 1
+
+    def _obj(self, type_, ref):
+        self.obj_type.append(type_)
+        self.obj_ref.append(ref)
+        return len(self.obj_type) - 1
+
+    def triangle(self, v, type_=api.TRIANGLE):
+        self.tris.append(np.asarray(v, F32).reshape(9))
+        return self._obj(type_, len(self.tris) - 1)
+
+    def sphere(self, center, radius, min_theta=0.0, max_theta=3.14159, phi=3.14159):
+        return self._obj(api.SPHERE, self._shape(api.SPHERE, list(center) + [radius, min_theta, max_theta, phi]))
+
+    def plane(self, point, normal):
+        return self._obj(api.PLANE, self._shape(api.PLANE, list(point) + list(normal)))
+
+    def rectangle(self, point, width, height):
+        normal = _normalize32(_cross32(width, height))         # parseRectEntry, scenefile.h:432-433
+        return self._obj(api.RECTANGLE, self._shape(api.RECTANGLE, list(point) + list(width) + list(height) + list(normal)))
+
+    def disk(self, center, normal, radius):
+        return self._obj(api.DISK, self._shape(api.DISK, list(center) + list(normal) + [radius]))
+
+    def box(self, inv_xform, x_span, y_span, z_span, shadow=True):
+        """initBox (shapes/box.cpp:4-20): AABox of half spans wrapped in an instance."""
+        hx, hy, hz = F32(x_span) / F32(2), F32(y_span) / F32(2), F32(z_span) / F32(2)
+        inner = self._shape(api.AABOX, [-hx, -hy, -hz, hx, hy, hz, 1.0 if shadow else 0.0])
+        return self._obj(api.INSTANCED, self._shape(api.INSTANCED, inner=inner, inv_xform=inv_xform))
+
+    def torus(self, inv_xform, swept_radius, tube_radius, phi=3.14159):
+        inner = self._shape(api.GENERICTORUS, [swept_radius, tube_radius, phi])
+        return self._obj(api.INSTANCED, self._shape(api.INSTANCED, inner=inner, inv_xform=inv_xform))
+
+    def open_cylinder(self, inv_xform, phi=3.14159):
+        """initOpenCylinder (shapes/cylinder.cpp:3-18): radius 1, half height 1."""
+        inner = self._shape(api.GENERICOPENCYLINDER, [1.0, 1.0, phi])
+        return self._obj(api.INSTANCED, self._shape(api.INSTANCED, inner=inner, inv_xform=inv_xform))
+
+    def solid_cylinder(self, inv_xform, radius, half_height, phi=3.14159):
+        """initSolidCylinder (shapes/cylinder.cpp:29-75): compound {top disk, bottom disk, tube}."""
+        first = self._shape(api.DISK, [0.0, half_height, 0.0, 0.0, 1.0, 0.0, radius])
+        self._shape(api.DISK, [0.0, -half_height, 0.0, 0.0, -1.0, 0.0, radius])
+        self._shape(api.GENERICOPENCYLINDER, [half_height, radius, phi])
+        comp = self._shape(api.COMPOUND, [-radius, -half_height, -radius, radius, half_height, radius],
+                           first_part=first, num_parts=3)
+        return self._obj(api.INSTANCED, self._shape(api.INSTANCED, inner=comp, inv_xform=inv_xform))
+
+    def to_input(self):
+        tri = np.array(self.tris, F32).reshape(-1, 9) if self.tris else np.zeros((0, 9), F32)
+        shapes = np.array(self.shapes, api.SHAPE_DTYPE) if self.shapes else np.zeros(0, api.SHAPE_DTYPE)
+        return api.SceneInput(tri, shapes, np.array(self.obj_type, np.int32), np.array(self.obj_ref, np.int32))
+
+
+def inv_transform(location, scale, euler_deg):
+    """inv_scale * inv_rotation * inv_translation as parseBoxEntry composes it (scenefile.h:497-503),
+    in float32.  rotation = Ry * (Rx * Rz) (eulerAngToMat4, util/math.cpp:80-93)."""
+    def rot(axis, deg):
+        th = F32(deg) * F32(math.pi / 180.0)
+        s, c = F32(math.sin(th)), F32(math.cos(th))
+        m = np.eye(4, dtype=F32)
+        if axis == "x":
+            m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, s, -s, c
+        elif axis == "y":
+            m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+        else:
+            m[0, 0], m[0, 1], m[1, 0], m[1, 1] = c, s, -s, c
+        return m
+    rz, rx, ry = rot("z", euler_deg[2]), rot("x", euler_deg[1]), rot("y", euler_deg[0])
+    rotation = (ry @ (rx @ rz)).astype(F32)
+    inv_rot = rotation.T.copy()
+    inv_scale = np.eye(4, dtype=F32)
+    for i in range(3):
+        inv_scale[i, i] = F32(1.0) / F32(scale[i])
+    inv_tr = np.eye(4, dtype=F32)
+    inv_tr[:3, 3] = -np.asarray(location, F32)
+    return ((inv_scale @ inv_rot).astype(F32) @ inv_tr).astype(F32)
+
+
+def cornell29():
+    """S1: 9 rectangles + 20 triangles, insertion order of cornell_box.txt."""
+    sl = ShapeList()
+    for r in CORNELL_RECTS:
+        sl.rectangle(r[0:3], r[3:6], r[6:9])
+    for t in CORNELL_TRIS:
+        sl.triangle(t, api.TRIANGLE)
+    return sl.to_input()
+
+
+def cube_tris(center, half):
+    c = np.asarray(center, F32)
+    h = F32(half)
+    v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)], F32) + c
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = []
+    for a, b, cc, d in quads:
+        tris.append(np.concatenate([v[a], v[b], v[cc]]))
+        tris.append(np.concatenate([v[a], v[cc], v[d]]))
+    return np.array(tris, F32)
+
+
+def analytic_scene(rotated=True):
+    """S2: the shapes of example_scene.txt:32-78 (sphere, plane, rectangle, triangle, disk) plus an
+    instanced box / torus(2.0, 0.1) / open cylinder / solid cylinder and a 12-triangle cube."""
+    sl = ShapeList()
+    sl.sphere((-2.0, 1.0, 0.0), 1.0)
+    sl.plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0))
+    sl.rectangle((1.0, -1.0, -3.0), (4.0, 0.0, 0.0), (0.0, 4.0, -4.0))
+    sl.triangle([3.0, 0.0, 2.0, 5.0, 0.0, 2.0, 4.0, 2.0, 2.0])
+    sl.disk((3.0, 3.0, 0.0), _normalize32((1.0, 0.0, 1.0)), 1.0)
+    e = (20.0, 35.0, 10.0) if rotated else (0.0, 0.0, 0.0)
+    s = (1.5, 0.75, 1.25) if rotated else (1.0, 1.0, 1.0)
+    sl.box(inv_transform((-4.0, 0.5, -2.0), s, e), 1.0, 2.0, 1.5)
+    sl.torus(inv_transform((0.0, 0.5, 3.0), (1.0, 1.0, 1.0) if not rotated else (1.0, 1.5, 1.0), e), 2.0, 0.1)
+    sl.open_cylinder(inv_transform((-1.0, 0.0, -4.0), s, e))
+    sl.solid_cylinder(inv_transform((5.0, 0.0, -1.0), s, e), 0.5, 1.0)
+    for t in cube_tris((2.0, 0.0, -1.0), 0.5):
+        sl.triangle(t, api.FLAT_TRIANGLE)
+    return sl.to_input()
+
+
+def random_tris(n, seed=1, extent=1.0, size=0.05):
+    """n small random triangles in [0, extent]^3 (the soup of SURVEY.md section 6)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.random((n, 1, 3), dtype=F32) * F32(extent)
+    d = (rng.random((n, 3, 3), dtype=F32) - F32(0.5)) * F32(2.0 * size)
+    return api.SceneInput((c + d).astype(F32).reshape(n, 9))
+
+
+# ---------------------------------------------------------------------------------------
+# procedural meshes for the large configurations
+
+def _value_noise(p, seed, octaves=3):
+    """cheap lattice value noise on points p [n,3] in float32, deterministic in seed."""
+    out = np.zeros(len(p), F32)
+    amp, freq = F32(1.0), F32(2.0)
+    for o in range(octaves):
+        q = p * freq
+        i = np.floor(q).astype(np.int64)
+        f = (q - i).astype(F32)
+        f = f * f * (F32(3.0) - F32(2.0) * f)
+        acc = np.zeros(len(p), F32)
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    h = ((i[:, 0] + dx) * 73856093) ^ ((i[:, 1] + dy) * 19349663) ^ ((i[:, 2] + dz) * 83492791) ^ (seed * 2654435761 + o)
+                    h = (h * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFF
+                    r = (h.astype(np.float64) / 4294967295.0).astype(F32)
+                    w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                    acc += r * w
+        out += amp * acc
+        amp *= F32(0.5)
+        freq *= F32(2.0)
+    return out
+
+
+def blob_mesh(n_lat, n_lon, seed, radius=1.0, displace=0.25):
+    """A noise-displaced lat-long sphere: 2 * n_lat * n_lon triangles (degenerate-free: the poles
+    are cut at a small cap angle).  Returns float32 [ntri, 9]."""
+    th = np.linspace(0.02 * math.pi, 0.98 * math.pi, n_lat + 1)
+    ph = np.linspace(0.0, 2.0 * math.pi, n_lon + 1)[:-1]
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    d = np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], -1).astype(F32)
+    r = F32(radius) * (F32(1.0) + F32(displace) * (_value_noise(d.reshape(-1, 3) * F32(1.5) + F32(3.0), seed) - F32(0.9)))
+    v = d * r.reshape(n_lat + 1, n_lon, 1)
+    a = v[:-1, :, :]
+    b = v[1:, :, :]
+    a2 = np.roll(a, -1, axis=1)
+    b2 = np.roll(b, -1, axis=1)
+    t1 = np.concatenate([a, b, b2], -1).reshape(-1, 9)
+    t2 = np.concatenate([a, b2, a2], -1).reshape(-1, 9)
+    return np.concatenate([t1, t2], 0).astype(F32)
+
+
+def _rot_matrix(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], F32)
+
+
+def room_tris(lo, hi):
+    """12 triangles: the six walls of an axis-aligned room."""
+    lo = np.asarray(lo, F32)
+    hi = np.asarray(hi, F32)
+    c = (lo + hi) * F32(0.5)
+    t = cube_tris((0, 0, 0), 1.0).reshape(-1, 3, 3)
+    return (t * ((hi - lo) * F32(0.5)) + c).reshape(-1, 9).astype(F32)
+
+
+def courtyard(n_copies, n_lat, n_lon, seed=5, room=10.0):
+    """S5-style stand-in for "San Miguel, instanced": a box room plus n_copies rotated, scaled,
+    translated copies of one displaced blob, FLATTENED to world space as generateMeshTriangles
+    does for every OBJECT MESH entry (buildscene.h:241-311).  2*n_lat*n_lon*n_copies + 12 triangles."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = blob_mesh(n_lat, n_lon, seed).reshape(-1, 3)
+    parts = [room_tris((0, 0, 0), (room, room * 0.5, room))]
+    for k in range(n_copies):
+        R = _rot_matrix(rng)
+        s = F32(0.15 + 0.35 * rng.random())
+        pos = np.array([rng.random() * room * 0.9 + room * 0.05, rng.random() * room * 0.4 + room * 0.05,
+                        rng.random() * room * 0.9 + room * 0.05], F32)
+        parts.append(((base @ R.T) * s + pos).astype(F32).reshape(-1, 9))
+    return api.SceneInput(np.concatenate(parts, 0))
+
+
+def buddha_like(n_lat=512, n_lon=1024, seed=3):
+    """S3-style stand-in for the ~1M-triangle Buddha: one finely displaced blob in a room."""
+    blob = blob_mesh(n_lat, n_lon, seed, radius=1.0, displace=0.45) * F32(0.4) + np.tile(np.array([0.5, 0.5, 0.5], F32), 3)
+    return api.SceneInput(np.concatenate([room_tris((0, 0, 0), (1, 1, 1)), blob.astype(F32)], 0))
+
+
+# ---------------------------------------------------------------------------------------
+# ray sets
+
+def scene_bounds(si):
+    v = si.tri_verts.reshape(-1, 3)
+    if len(v) == 0:
+        return np.array([-6, -2, -6], F32), np.array([6, 4, 6], F32)
+    return v.min(0), v.max(0)
+
+
+def random_rays(n, lo, hi, seed=0xC0FFEE):
+    """origins uniform in [lo, hi], directions uniform on the sphere (unit length, float32)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    o = (rng.random((n, 3), dtype=F32) * (np.asarray(hi, F32) - np.asarray(lo, F32)) + np.asarray(lo, F32)).astype(F32)
+    d = rng.normal(size=(n, 3)).astype(F32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(F32)
+    return np.concatenate([o, d.astype(F32)], 1).astype(F32)
+
+
+def camera_rays(width, height, eye, look, fov_deg=40.0, seed=None):
+    """pinhole rays through pixel centres (coherent; sanity only)."""
+    eye = np.asarray(eye, np.float64)
+    w = eye - np.asarray(look, np.float64)
+    w /= np.linalg.norm(w)
+    u = np.cross([0.0072, 1.0, 0.0034], w)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    half = math.tan(math.radians(fov_deg) / 2)
+    xs = ((np.arange(width) + 0.5) / width * 2 - 1) * half * width / height
+    ys = ((np.arange(height) + 0.5) / height * 2 - 1) * half
+    X, Y = np.meshgrid(xs, ys)
+    d = X[..., None] * u + Y[..., None] * v - w
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(eye, d.shape)
+    return np.concatenate([o, d], -1).reshape(-1, 6).astype(F32)
+
+
+def axis_parallel_rays(n, lo, hi, seed=7):
+    """rays with one or two exactly-zero (and some -0.0) direction components: classes T2/T3."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r = random_rays(n, lo, hi, seed)
+    k = rng.integers(0, 3, n)
+    r[np.arange(n), 3 + k] = 0.0
+    neg = rng.random(n) < 0.25
+    r[neg, 3 + k[neg]] = F32(-0.0)
+    two = rng.random(n) < 0.2
+    k2 = (k + 1) % 3
+    r[two, 3 + k2[two]] = 0.0
+    nrm = np.linalg.norm(r[:, 3:], axis=1, keepdims=True)
+    nrm[nrm == 0] = 1
+    r[:, 3:] = (r[:, 3:] / nrm).astype(F32)
+    return r.astype(F32)
+
+
+def tri_normals(tri_verts, ids):
+    t = tri_verts[ids].reshape(-1, 3, 3).astype(np.float64)
+    n = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    ln[ln == 0] = 1
+    return n / ln
+
+
+def bounce_rays(trace, si, primary, bounces=3, seed=0xC0FFEE, keep_primary=False):
+    """R-incoherent: trace `primary`, spawn a cosine-hemisphere direction about the
+    geometric normal at every hit (origin = hit point, no offset: resetRay, trace.h:496), repeat;
+    return the concatenated, shuffled bounce-1..bounces rays.  `trace(rays) -> HIT_DTYPE[n]` is
+    the engine under test or the oracle; triangle-only scenes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = [primary] if keep_primary else []
+    rays = primary
+    for _ in range(bounces):
+        hits = trace(rays)
+        ok = hits["obj"] >= 0
+        if not ok.any():
+            break
+        r = rays[ok]
+        h = hits[ok]
+        p = (r[:, :3].astype(np.float64) + r[:, 3:].astype(np.float64) * h["t"].astype(np.float64)[:, None])
+        n = tri_normals(si.tri_verts, h["obj"])
+        flip = (n * r[:, 3:]).sum(1) > 0
+        n[flip] = -n[flip]
+        u1, u2 = rng.random(len(r)), rng.random(len(r))
+        rr, ph = np.sqrt(u1), 2 * math.pi * u2
+        a = np.where(np.abs(n[:, :1]) > 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+        tx = np.cross(a, n)
+        tx /= np.linalg.norm(tx, axis=1, keepdims=True)
+        ty = np.cross(n, tx)
+        d = tx * (rr * np.cos(ph))[:, None] + ty * (rr * np.sin(ph))[:, None] + n * np.sqrt(np.maximum(0, 1 - u1))[:, None]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([p, d], 1).astype(F32)
+        out.append(rays)
+    allr = np.concatenate(out, 0)
+    rng.shuffle(allr, axis=0)
+    return np.ascontiguousarray(allr, F32)
+
+
+def shadow_rays_toward(points, lo, hi, seed=11):
+    """shadow rays from `points` toward uniformly sampled points in the box [lo, hi] (a light),
+    light_dist = distance (trace.h:253-260,:337)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tgt = rng.random((len(points), 3)) * (np.asarray(hi, np.float64) - np.asarray(lo, np.float64)) + np.asarray(lo, np.float64)
+    d = tgt - points.astype(np.float64)
+    dist = np.linalg.norm(d, axis=1)
+    dist[dist == 0] = 1
+    d /= dist[:, None]
+    return np.concatenate([points, d], 1).astype(F32), dist.astype(F32)

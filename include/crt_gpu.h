@@ -1,0 +1,226 @@
+/*
+ * crt_gpu.h -- C ABI of the MI355X (gfx950) ray traversal + intersection engine
+ * that sits behind craytracer's scene-intersection API.
+ *
+ * Drop-in boundary.  The reference has no FFI layer: its hot path
+ * is two free functions,
+ *     float intersectTest(ShadeRec*, const SceneObjects*, const Ray)            intersect.h:365
+ *     float shadowIntersectTest(const SceneObjects*, const Ray, float light_dist) intersect.h:443
+ * over a `SceneObjects` handle (scene/scenedata.h:20-28) whose accelerator was
+ * built by buildSceneAccel (buildscene.h:698-731).  This header is what a
+ * maintainer binds instead: a flat scene description goes in once, ray batches
+ * go in, hit records come out.  Plain C, plain pointers and sizes; no torch or
+ * HIP types appear in any signature (streams are passed as void*).
+ *
+ * All functions return 0 (CRT_OK) or a negative CRT_E_* code; nothing throws,
+ * nothing calls exit().  A miss is data (t == CRT_TMAX, obj == -1), not an error.
+ */
+#ifndef CRT_GPU_H
+#define CRT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants: util/constants.h:45-50 -------------------------------- */
+#define CRT_K_EPSILON   0.000007f               /* K_EPSILON */
+#define CRT_TMAX        3.402823466e+38F        /* TMAX == FLT_MAX */
+#define CRT_K_FLAT_AABB 0.001f                  /* K_FLAT_AABB */
+#define CRT_HUGEVALUE   1.0E10f                 /* HUGEVALUE */
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+    CRT_OK            =  0,
+    CRT_E_INVALID     = -1,   /* bad argument / inconsistent description       */
+    CRT_E_NOMEM       = -2,   /* host or device allocation failed              */
+    CRT_E_HIP         = -3,   /* a HIP runtime call failed (see crt_last_hip_error) */
+    CRT_E_UNSUPPORTED = -4,   /* valid request this build does not implement   */
+    CRT_E_TOOBIG      = -5,   /* size beyond a documented limit                */
+    CRT_E_NODEVICE    = -6    /* no usable gfx950 device                       */
+};
+
+/* ---- enums mirrored from the reference -------------------------------- */
+/* ObjectType, shapes/objecttype.h:4-18 (same numeric values). */
+enum crt_prim_type {
+    CRT_SPHERE = 0, CRT_PLANE = 1, CRT_RECTANGLE = 2, CRT_AABOX = 3, CRT_TRIANGLE = 4,
+    CRT_GENERICOPENCYLINDER = 5, CRT_DISK = 6, CRT_GENERICTORUS = 7, CRT_INSTANCED = 8,
+    CRT_COMPOUND = 9, CRT_FLAT_TRIANGLE = 10, CRT_SMOOTH_TRIANGLE = 11
+};
+/* AccelType, scene/scenedata.h:12-18 (same numeric values). */
+enum crt_accel { CRT_ACCEL_NONE = 0, CRT_ACCEL_GRID = 1, CRT_ACCEL_BVH = 2, CRT_ACCEL_BVH4 = 3 };
+
+/* Traversal semantics for closest-hit on BVH / BVH4.
+ *  CRT_TRAVERSE_PRUNED : best-t pruning against the ray's global nearest hit, in the
+ *      reference's child order.  Identical result whenever every primitive's hit lies
+ *      inside its (padded) box -- true for triangles, K_FLAT_AABB pad (shapes.cpp:207-211).
+ *  CRT_TRAVERSE_EXACT  : the reference's own control flow -- BVH4: min_t local to each
+ *      node visit (bvh4.h:354); BVH: both overlapped children, no pruning
+ *      (intersect.h:310-342).  Needed when boxes are not bounding (rotated/scaled
+ *      instances, shapes.cpp:284-304).
+ *  CRT_TRAVERSE_AUTO   : EXACT if the scene holds any non-triangle object below the
+ *      accelerator, else PRUNED. */
+enum crt_traverse_mode { CRT_TRAVERSE_AUTO = 0, CRT_TRAVERSE_PRUNED = 1, CRT_TRAVERSE_EXACT = 2 };
+
+/* ---- ray and hit records ---------------------------------------------- */
+/* Bit-identical to `Ray` (util/ray.h:5-9): origin[3], direction[3]; 24 bytes. */
+typedef struct crt_ray { float o[3]; float d[3]; } crt_ray;
+
+/* What intersectTest returns, minus the 352-byte ShadeRec (util/shaderec.h:7-19),
+ * which the host rebuilds from these five words.
+ *   t     : hit distance, CRT_TMAX on miss (intersect.h:372).
+ *   obj   : INSERTION-ORDER index of the hit object (SURVEY 8a "Primitive ID"), -1 on miss.
+ *   part  : index inside a CompoundObject (instanced.cpp:164), else 0; -1 on miss.
+ *   beta,gamma : triangle barycentrics as calcTriangleIntersect writes them
+ *           (triangle.cpp:44-45); 0 for other shapes and on miss. */
+typedef struct crt_hit { float t; int32_t obj; int32_t part; float beta; float gamma; } crt_hit;
+
+/* ---- analytic shapes --------------------------------------------------- */
+/* One non-triangle shape.  p[] holds the geometric fields of the reference struct:
+ *   SPHERE   (sphere.h:10-17)   p = center[3], radius, min_theta, max_theta, phi
+ *   PLANE    (plane.h:8-14)     p = point[3], normal[3]
+ *   RECTANGLE(rect.h:9-16)      p = point[3], width[3], height[3], normal[3]
+ *   AABOX    (generic.h AABox)  p = min[3], max[3], shadow (0/1)
+ *   GENERICOPENCYLINDER         p = half_height, radius, phi
+ *   DISK     (disk.h:9-16)      p = center[3], normal[3], radius
+ *   GENERICTORUS                p = swept_radius, tube_radius, phi
+ *   COMPOUND (instanced.h:7-13) p = aabb.min[3], aabb.max[3]; parts = shapes[first_part .. first_part+num_parts)
+ *   INSTANCED(instanced.h:15-20) inner = index in shapes[] of the wrapped shape;
+ *                               inv_xform = row-major inv_transform (mat4) */
+typedef struct crt_shape {
+    int32_t type;
+    int32_t inner;
+    int32_t first_part;
+    int32_t num_parts;
+    float   p[12];
+    float   inv_xform[16];
+} crt_shape;
+
+/* ---- scene input: objects in INSERTION order --------------------------- */
+/* Equivalent of the SceneObjects array after SceneObjects_push_obj calls
+ * (scenedata.h:40-48) and before mvNonGridObjToStart / the builders reorder it.
+ * obj_type[i] in {TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE}: obj_ref[i] indexes
+ * tri_verts (9 floats: v0, v1, v2); otherwise obj_ref[i] indexes shapes[].
+ * obj_type == NULL means "num_obj triangles, object i = triangle i, type SMOOTH_TRIANGLE". */
+typedef struct crt_scene_input {
+    int32_t         num_obj;
+    const int32_t*  obj_type;
+    const int32_t*  obj_ref;
+    const float*    tri_verts;
+    int32_t         num_tris;
+    const crt_shape* shapes;
+    int32_t         num_shapes;
+} crt_scene_input;
+
+/* ---- built accelerator, flat, host memory ------------------------------ */
+/* QBVH node: BVHNode4 (bvh4.h:100-110) with pointers turned into indices.
+ *   bbox   : minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4]   (bvh4.h:105)
+ *   child  : type == -1 -> index into nodes4[]; else index of the leaf's first
+ *            object in the FINAL objects[] order (absolute, non-grid prefix included)
+ *   type   : -1 inner, else 0..4 leaf object count               (bvh4.h:107)
+ *   axis   : the byte BVH4_build leaves in node->axis (third split axis; bvh4.h:194-195) */
+typedef struct crt_bvh4_node {
+    float   bbox[24];
+    int32_t child[4];
+    int8_t  type[4];
+    uint8_t axis;
+    uint8_t pad[11];
+} crt_bvh4_node;                                   /* 128 bytes */
+
+/* Binary BVH node: BVHNode (bvh.h:19-26).  Leaf: left == -1, obj = object index. */
+typedef struct crt_bvh2_node {
+    float   bmin[3];
+    float   bmax[3];
+    int32_t left;      /* -1 for a leaf, else index of left child  */
+    int32_t right;     /* leaf: FINAL-order object index; else right child */
+} crt_bvh2_node;                                   /* 32 bytes */
+
+/* UniformGrid (uniformgrid.h:10-17); cells as CSR instead of IntVector. */
+typedef struct crt_grid {
+    int32_t nx, ny, nz, num_cells;
+    float   wx, wy, wz;
+    float   bmin[3], bmax[3];
+} crt_grid;
+
+/* Scene as intersectTest sees it: FINAL objects[] order + one accelerator. */
+typedef struct crt_scene_desc {
+    int32_t accel;                 /* crt_accel */
+    int32_t num_obj;
+    int32_t num_non_grid_obj;      /* objects[0..num_non_grid_obj) are tested linearly */
+    const int32_t* obj_type;       /* [num_obj] */
+    const int32_t* obj_ref;        /* [num_obj] */
+    const int32_t* obj_id;         /* [num_obj] insertion-order id reported in crt_hit.obj */
+    const float*   tri_verts;      /* [num_tris*9] */
+    int32_t        num_tris;
+    const crt_shape* shapes;
+    int32_t        num_shapes;
+    const crt_bvh4_node* nodes4;   /* BVH4: nodes4[0] is the root */
+    int32_t        num_nodes4;
+    const crt_bvh2_node* nodes2;   /* BVH: nodes2[0] is the root */
+    int32_t        num_nodes2;
+    crt_grid       grid;           /* GRID */
+    const int32_t* cell_start;     /* [num_cells+1] */
+    const int32_t* cell_items;     /* [cell_start[num_cells]] FINAL-order object indices */
+} crt_scene_desc;
+
+/* ---- host-side build (the reference's host keeps doing this; provided so the
+ *      library is usable stand-alone) ------------------------------------- */
+typedef struct crt_built_scene crt_built_scene;     /* owns the arrays a crt_scene_desc points to */
+
+/* mvNonGridObjToStart (scenedata.h:368-382) + buildSceneAccel (buildscene.h:698-731):
+ * UniformGrid_create (uniformgrid.h:54-154, multiplier 3) | BVH_build (bvh.h:117-154) |
+ * BVH4_build (bvh4.h:127-297).  Sorts are stable (see DESIGN.md "builder order"). */
+int  crt_build_scene(const crt_scene_input* in, int accel, crt_built_scene** out);
+const crt_scene_desc* crt_built_scene_desc(const crt_built_scene* b);
+void crt_built_scene_destroy(crt_built_scene* b);
+
+/* ---- device scene ------------------------------------------------------ */
+typedef struct crt_scene crt_scene;                 /* opaque; owns device memory */
+
+int  crt_device_count(int* count);
+/* Upload `desc` to HBM of `device` in the kernel layout.  No host pointer is retained. */
+int  crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out);
+void crt_scene_destroy(crt_scene* s);
+/* crt_traverse_mode for closest-hit; default CRT_TRAVERSE_AUTO. */
+int  crt_scene_set_traverse_mode(crt_scene* s, int mode);
+int  crt_scene_get_traverse_mode(const crt_scene* s, int* resolved_mode);
+
+/* n x intersectTest (intersect.h:365-440).  Host buffers; copies in and out. */
+int  crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits);
+/* n x shadowIntersectTest (intersect.h:443-545) + the caller's test
+ * `in_shadow = t < light_dist - K_EPSILON` (trace.h:348).  t_out[i] is the value the
+ * reference function returns; occluded_out[i] the caller's boolean. Either may be NULL. */
+int  crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist, size_t n,
+                      float* t_out, uint8_t* occluded_out);
+
+/* Same, all pointers DEVICE pointers on the scene's GPU; enqueued on `stream`
+ * (a hipStream_t passed as void*, NULL = the null stream); returns without syncing. */
+int  crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream);
+int  crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                          float* d_t_out, uint8_t* d_occluded_out, void* stream);
+
+/* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)
+ * and g_intersect_count (shapes.cpp:3).  Counting is off by default (it costs atomics);
+ * when on, kernels add per-ray node / primitive-test counts. */
+typedef struct crt_counters {
+    uint64_t rays_closest, rays_shadow;
+    uint64_t nodes_visited;       /* BVH/BVH4 nodes whose boxes were tested; GRID: cells walked */
+    uint64_t prims_tested;        /* rayIntersectObject / shadowRayIntersectObject calls */
+} crt_counters;
+int  crt_scene_enable_counters(crt_scene* s, int on);
+int  crt_scene_get_counters(crt_scene* s, crt_counters* out);   /* syncs the device */
+int  crt_scene_reset_counters(crt_scene* s);
+
+/* Duration in milliseconds of the most recent traversal kernel launched through this
+ * scene, measured with HIP events on the stream it was launched on (syncs). */
+int  crt_scene_last_kernel_ms(crt_scene* s, float* ms);
+
+const char* crt_strerror(int code);
+const char* crt_last_hip_error(void);               /* text of the last failing HIP call */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_GPU_H */

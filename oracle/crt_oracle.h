@@ -1,0 +1,58 @@
+/*
+ * crt_oracle.h -- CPU restatement of craytracer's traversal + intersection path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * only as the checker / reported baseline.  The product (craytracer_amd/) never
+ * links or calls it.
+ *
+ * Pinning: validated in the build container against oracle/_ref (the reference's
+ * own builders, QBVH traversal, box tests and primitive intersectors compiled from
+ * /root/reference) by tests/test_oracle_vs_ref.py, and against the committed golden
+ * vectors under tests/golden/ (generated from oracle/_ref by tests/golden/make_golden.py).
+ * Not covered by oracle/_ref: the functions that live in intersect.h itself
+ * (grid walk, binary-BVH recursion, dispatch) -- that header includes <GLFW/glfw3.h>,
+ * which the image lacks, so it is unbuildable here; those three are restated from
+ * the text and cross-checked against NONE/BVH4 results on the same rays.
+ */
+#ifndef CRT_ORACLE_H
+#define CRT_ORACLE_H
+#include "../include/crt_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_scene oracle_scene;
+
+/* mvNonGridObjToStart + buildSceneAccel restated.  sort_mode: 0 = stable sort for every
+ * range (deterministic; what the product's builder does), 1 = the reference's own
+ * insertion-sort / rand()-pivot quicksort (bvh.h:56-112), for comparison with oracle/_ref. */
+oracle_scene* oracle_scene_create(const crt_scene_input* in, int accel, int sort_mode);
+void          oracle_scene_destroy(oracle_scene* s);
+
+/* Final objects[] order as insertion ids; returns num_obj.  ids may be NULL. */
+int  oracle_scene_order(const oracle_scene* s, int32_t* ids, int32_t* num_non_grid);
+/* Flattened accelerator, same numbering rule as the product (pre-order DFS, children in
+ * slot order).  Pass NULL to query counts. */
+int  oracle_scene_nodes4(const oracle_scene* s, crt_bvh4_node* out);
+int  oracle_scene_nodes2(const oracle_scene* s, crt_bvh2_node* out);
+int  oracle_scene_grid(const oracle_scene* s, crt_grid* g, int32_t* cell_start, int32_t* cell_items);
+
+/* mode: CRT_TRAVERSE_EXACT = the reference's control flow; CRT_TRAVERSE_PRUNED = best-t
+ * pruned, reference child order (the traversal the algorithmic-bytes counters are defined on).
+ * counters (may be NULL) accumulates nodes_visited / prims_tested.  nthreads >= 1. */
+void oracle_intersect(const oracle_scene* s, const crt_ray* rays, size_t n, crt_hit* hits,
+                      int mode, crt_counters* counters, int nthreads);
+void oracle_shadow(const oracle_scene* s, const crt_ray* rays, const float* light_dist, size_t n,
+                   float* t_out, uint8_t* occluded_out, crt_counters* counters, int nthreads);
+
+/* Single-primitive entry points (for leaf-level tests). */
+float oracle_intersect_object(const oracle_scene* s, int final_index, const crt_ray* ray, crt_hit* hit);
+float oracle_shadow_object(const oracle_scene* s, int final_index, const crt_ray* ray);
+float oracle_ray_aabb(const float bmin[3], const float bmax[3], const crt_ray* ray);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,423 @@
+/*
+ * ref_harness.cpp -- builds oracle/_ref/libcrt_ref.so around the REFERENCE's own code.
+ *
+ * TEST INFRASTRUCTURE ONLY, usable only in the build container (it compiles sources
+ * where they lie under /root/reference; nothing of the reference is copied here).
+ * This file contains no reference code: it constructs scenes through the reference's
+ * structs (Triangle, Sphere, Rectangle, ..., InstancedShape via initBox/initTorus/
+ * initOpenCylinder/initSolidCylinder), runs the reference's builders
+ * (UniformGrid_create, BVH_build, BVH4_build), traversals (BVH4IntersectTest,
+ * BVH4ShadowIntersectTest) and intersectors (rayIntersectObject, shadowRayIntersectObject,
+ * rayIntersectAABB), and flattens what they produce into the crt_* layouts so the
+ * restatement in crt_oracle.cpp can be compared with it bit for bit.
+ *
+ * NOT reachable from here: intersect.h (includes <GLFW/glfw3.h>, absent from the image,
+ * and no stand-in is written) -> gridIntersectTest, BVHIntersectTest, intersectTest and
+ * shadowIntersectTest themselves.  The few lines of intersectTest's BVH4/NONE branches
+ * (intersect.h:397-432, :470-498) are re-expressed below as harness code around the
+ * reference's BVH4*Test / *IntersectObject functions; this is noted in DESIGN.md.
+ *
+ * Object ids: rayIntersectObject / shadowRayIntersectObject calls made from inside the
+ * reference's traversal are routed through a hook (macro rename applied only to the
+ * accelerator headers) that logs (object pointer, t).  Every accept test in the reference
+ * is a strict `<`, so the winner is the first logged call whose t equals the returned t.
+ */
+#include "../include/crt_gpu.h"
+
+#include "shapes/shapes.h"
+#include "shapes/instanced.h"
+#include "aabb.h"
+#include "util/math.h"
+
+#include <vector>
+#include <unordered_map>
+
+struct RefLogEntry { void* ptr; float t; };
+static thread_local std::vector<RefLogEntry>* g_log = 0;
+
+static float hook_rayIntersectObject(ShadeRec* sr, const Object_t obj, const Ray ray)
+{
+    float t = rayIntersectObject(sr, obj, ray);
+    if (g_log) g_log->push_back(RefLogEntry{ obj.ptr, t });
+    return t;
+}
+static float hook_shadowRayIntersectObject(const Object_t obj, const Ray ray)
+{
+    float t = shadowRayIntersectObject(obj, ray);
+    if (g_log) g_log->push_back(RefLogEntry{ obj.ptr, t });
+    return t;
+}
+
+#define rayIntersectObject hook_rayIntersectObject
+#define shadowRayIntersectObject hook_shadowRayIntersectObject
+#include "accelerator/uniformgrid.h"
+#include "accelerator/bvh4.h"
+#undef rayIntersectObject
+#undef shadowRayIntersectObject
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+struct ref_scene {
+    int accel;
+    int num_obj, num_non_grid;
+    Object_t* objects;
+    std::unordered_map<void*, int> id_of;
+    BVHNode4* tree4;
+    BVHNode* tree2;
+    UniformGrid* grid;
+    Material* mat;
+    Mesh* mesh;
+};
+
+static void* make_shape(const crt_scene_input* in, int si, int* type_out, Material* mat);
+
+static Object_t make_object(const crt_scene_input* in, int si, Material* mat)
+{
+    Object_t o;
+    int type;
+    o.ptr = make_shape(in, si, &type, mat);
+    o.type = (ObjectType)type;
+    return o;
+}
+
+static void* make_shape(const crt_scene_input* in, int si, int* type_out, Material* mat)
+{
+    const crt_shape& sh = in->shapes[si];
+    const float* p = sh.p;
+    *type_out = sh.type;
+    switch (sh.type) {
+    case CRT_SPHERE: {
+        Sphere* s = (Sphere*)calloc(1, sizeof(Sphere));
+        vec3_assign(s->center, p[0], p[1], p[2]);
+        s->radius = p[3]; s->min_theta = p[4]; s->max_theta = p[5]; s->phi = p[6]; s->mat = mat;
+        return s;
+    }
+    case CRT_PLANE: {
+        Plane* s = (Plane*)calloc(1, sizeof(Plane));
+        vec3_assign(s->point, p[0], p[1], p[2]);
+        vec3_assign(s->normal, p[3], p[4], p[5]);
+        s->mat = mat;
+        return s;
+    }
+    case CRT_RECTANGLE: {
+        Rectangle* s = (Rectangle*)calloc(1, sizeof(Rectangle));
+        vec3_assign(s->point, p[0], p[1], p[2]);
+        vec3_assign(s->width, p[3], p[4], p[5]);
+        vec3_assign(s->height, p[6], p[7], p[8]);
+        vec3_assign(s->normal, p[9], p[10], p[11]);
+        s->mat = mat;
+        return s;
+    }
+    case CRT_AABOX: {
+        AABox* s = (AABox*)calloc(1, sizeof(AABox));
+        vec3_assign(s->min, p[0], p[1], p[2]);
+        vec3_assign(s->max, p[3], p[4], p[5]);
+        s->shadow = (p[6] != 0.0f);
+        s->mat = mat;
+        return s;
+    }
+    case CRT_GENERICOPENCYLINDER: {
+        GenericOpenCylinder* s = (GenericOpenCylinder*)calloc(1, sizeof(GenericOpenCylinder));
+        s->half_height = p[0]; s->radius = p[1]; s->phi = p[2]; s->normal_type = OPEN; s->mat = mat;
+        return s;
+    }
+    case CRT_DISK: {
+        Disk* s = (Disk*)calloc(1, sizeof(Disk));
+        vec3_assign(s->center, p[0], p[1], p[2]);
+        vec3_assign(s->normal, p[3], p[4], p[5]);
+        s->radius = p[6]; s->mat = mat;
+        return s;
+    }
+    case CRT_GENERICTORUS: {
+        GenericTorus* s = (GenericTorus*)calloc(1, sizeof(GenericTorus));
+        s->swept_radius = p[0]; s->tube_radius = p[1]; s->phi = p[2]; s->mat = mat;
+        return s;
+    }
+    case CRT_COMPOUND: {
+        CompoundObject* c = (CompoundObject*)calloc(1, sizeof(CompoundObject));
+        c->num_obj = sh.num_parts;
+        c->objects = (Object_t*)calloc(sh.num_parts, sizeof(Object_t));
+        for (int i = 0; i < sh.num_parts; i++) c->objects[i] = make_object(in, sh.first_part + i, mat);
+        vec3_assign(c->aabb.min, p[0], p[1], p[2]);
+        vec3_assign(c->aabb.max, p[3], p[4], p[5]);
+        return c;
+    }
+    case CRT_INSTANCED: {
+        InstancedShape* is = (InstancedShape*)calloc(1, sizeof(InstancedShape));
+        is->obj = make_object(in, sh.inner, mat);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) is->inv_transform[r][c] = sh.inv_xform[4*r + c];
+        is->mat = mat;
+        return is;
+    }
+    }
+    return 0;
+}
+
+REF_API ref_scene* ref_scene_create(const crt_scene_input* in, int accel)
+{
+    ref_scene* s = new ref_scene();
+    s->accel = accel;
+    s->tree4 = 0; s->tree2 = 0; s->grid = 0;
+    s->mat = (Material*)calloc(1, sizeof(Material));
+    s->mesh = (Mesh*)calloc(1, sizeof(Mesh));
+    s->num_obj = in->num_obj;
+    s->objects = (Object_t*)calloc(in->num_obj > 0 ? in->num_obj : 1, sizeof(Object_t));
+    for (int i = 0; i < in->num_obj; i++) {
+        int type = in->obj_type ? in->obj_type[i] : (int)CRT_TRIANGLE;
+        int ref = in->obj_type ? in->obj_ref[i] : i;
+        Object_t o;
+        if (type == CRT_TRIANGLE || type == CRT_SMOOTH_TRIANGLE || type == CRT_FLAT_TRIANGLE) {
+            /* All three triangle kinds share calcTriangleIntersect (triangle.cpp:14-77) for the hit
+             * arithmetic.  SmoothTriangle's wrapper dereferences mesh normals/tangents
+             * (triangle.cpp:224-251) and FlatTriangle's wraps an UNINITIALISED sr->uv with
+             * `while(uv > 1) uv -= 1` (triangle.cpp:195-198), which never ends for a large garbage
+             * value; both are shading-side effects, so every triangle is built as a plain Triangle. */
+            Triangle* t = (Triangle*)calloc(1, sizeof(Triangle));
+            const float* v = in->tri_verts + (size_t)ref * 9;
+            vec3_assign(t->v0, v[0], v[1], v[2]);
+            vec3_assign(t->v1, v[3], v[4], v[5]);
+            vec3_assign(t->v2, v[6], v[7], v[8]);
+            calcTriangleNormal(t->normal, t->v0, t->v1, t->v2);
+            t->mat = s->mat;
+            o.type = TRIANGLE; o.ptr = t;
+        } else {
+            o = make_object(in, ref, s->mat);
+        }
+        s->objects[i] = o;
+        s->id_of[o.ptr] = i;
+    }
+    /* mvNonGridObjToStart (scene/scenedata.h:368-382) lives in a header that pulls in the
+     * OBJ loader and texture code; its 10 lines are re-expressed here around the reference's
+     * isGridObjType. */
+    int j = 0;
+    for (int i = 0; i < s->num_obj; ++i) {
+        if (!isGridObjType(s->objects[i])) {
+            Object_t tmp = s->objects[i]; s->objects[i] = s->objects[j]; s->objects[j] = tmp; ++j;
+        }
+    }
+    s->num_non_grid = j;
+    int n_accel = s->num_obj - j;
+    if (accel == CRT_ACCEL_GRID) {
+        int n = s->num_obj;
+        s->grid = UniformGrid_create(s->objects, &n, s->num_non_grid, 3);
+    } else if (accel == CRT_ACCEL_BVH && n_accel > 0) {
+        BVH_build(&s->tree2, &(s->objects[j]), n_accel);
+    } else if (accel == CRT_ACCEL_BVH4 && n_accel > 0) {
+        BVH4_build(&s->tree4, &(s->objects[j]), n_accel);
+    }
+    return s;
+}
+
+REF_API int ref_scene_order(const ref_scene* s, int32_t* ids, int32_t* num_non_grid)
+{
+    if (ids) for (int i = 0; i < s->num_obj; i++) ids[i] = s->id_of.at(s->objects[i].ptr);
+    if (num_non_grid) *num_non_grid = s->num_non_grid;
+    return s->num_obj;
+}
+
+static int flatten4(const ref_scene* s, const BVHNode4* n, std::vector<crt_bvh4_node>* out)
+{
+    int self = (int)out->size();
+    out->push_back(crt_bvh4_node());
+    crt_bvh4_node nd;
+    memset(&nd, 0, sizeof nd);
+    memcpy(nd.bbox, n->bbox, sizeof(float) * 24);
+    nd.axis = n->axis;
+    for (int c = 0; c < 4; c++) {
+        nd.type[c] = n->type[c];
+        if (n->type[c] == -1) nd.child[c] = flatten4(s, (const BVHNode4*)n->child[c], out);
+        else nd.child[c] = (int)((const Object_t*)n->child[c] - s->objects);
+    }
+    (*out)[self] = nd;
+    return self;
+}
+REF_API int ref_scene_nodes4(const ref_scene* s, crt_bvh4_node* out)
+{
+    std::vector<crt_bvh4_node> v;
+    if (s->tree4) flatten4(s, s->tree4, &v);
+    if (out) memcpy(out, v.data(), v.size() * sizeof(crt_bvh4_node));
+    return (int)v.size();
+}
+
+static int flatten2(const ref_scene* s, const BVHNode* n, std::vector<crt_bvh2_node>* out)
+{
+    int self = (int)out->size();
+    out->push_back(crt_bvh2_node());
+    crt_bvh2_node nd;
+    for (int k = 0; k < 3; k++) { nd.bmin[k] = n->aabb.min[k]; nd.bmax[k] = n->aabb.max[k]; }
+    if (n->type == LEAF) {
+        nd.left = -1;
+        int idx = -1;
+        for (int i = 0; i < s->num_obj; i++) if (s->objects[i].ptr == n->obj.ptr) { idx = i; break; }
+        nd.right = idx;
+    } else {
+        nd.left = flatten2(s, n->left, out);
+        nd.right = flatten2(s, n->right, out);
+    }
+    (*out)[self] = nd;
+    return self;
+}
+REF_API int ref_scene_nodes2(const ref_scene* s, crt_bvh2_node* out)
+{
+    std::vector<crt_bvh2_node> v;
+    if (s->tree2) flatten2(s, s->tree2, &v);
+    if (out) memcpy(out, v.data(), v.size() * sizeof(crt_bvh2_node));
+    return (int)v.size();
+}
+
+REF_API int ref_scene_grid(const ref_scene* s, crt_grid* g, int32_t* cell_start, int32_t* cell_items)
+{
+    const UniformGrid* ug = s->grid;
+    if (!ug) return -1;
+    if (g) {
+        g->nx = ug->nx; g->ny = ug->ny; g->nz = ug->nz; g->num_cells = ug->num_cells;
+        g->wx = ug->wx; g->wy = ug->wy; g->wz = ug->wz;
+        for (int k = 0; k < 3; k++) { g->bmin[k] = ug->aabb.min[k]; g->bmax[k] = ug->aabb.max[k]; }
+    }
+    int total = 0;
+    for (int c = 0; c < ug->num_cells; c++) {
+        if (cell_start) cell_start[c] = total;
+        for (int i = 0; i < ug->cells[c].size; i++) { if (cell_items) cell_items[total] = ug->cells[c].array[i]; total++; }
+    }
+    if (cell_start) cell_start[ug->num_cells] = total;
+    return total;
+}
+
+static void to_ray(Ray* r, const crt_ray* in)
+{
+    vec3_assign(r->origin, in->o[0], in->o[1], in->o[2]);
+    vec3_assign(r->direction, in->d[0], in->d[1], in->d[2]);
+}
+
+/* part index + barycentrics of the winning object, recomputed with the reference's functions */
+static void fill_details(const ref_scene* s, void* ptr, const Ray ray, crt_hit* out)
+{
+    out->part = 0; out->beta = 0; out->gamma = 0;
+    Object_t obj; obj.ptr = 0; obj.type = SPHERE;
+    for (int i = 0; i < s->num_obj; i++) if (s->objects[i].ptr == ptr) { obj = s->objects[i]; break; }
+    if (obj.type == TRIANGLE) {
+        Triangle* t = (Triangle*)obj.ptr;
+        calcTriangleIntersect(&out->beta, &out->gamma, t->v0, t->v1, t->v2, ray);
+    } else if (obj.type == INSTANCED) {
+        InstancedShape* is = (InstancedShape*)obj.ptr;
+        if (is->obj.type == COMPOUND) {
+            Ray r2;
+            transformRay(&r2, is->inv_transform, ray);
+            CompoundObject* co = (CompoundObject*)is->obj.ptr;
+            float min_t = TMAX;
+            for (int i = 0; i < co->num_obj; i++) {
+                ShadeRec tmp;
+                float t = rayIntersectObject(&tmp, co->objects[i], r2);
+                if (t < min_t) { min_t = t; out->part = i; }
+            }
+        }
+    }
+}
+
+/* n x { BVH4 / NONE branch of intersectTest (intersect.h:397-432) } on the reference's functions */
+REF_API int ref_intersect(const ref_scene* s, const crt_ray* rays, size_t n, crt_hit* hits)
+{
+    if (s->accel != CRT_ACCEL_BVH4 && s->accel != CRT_ACCEL_NONE) return CRT_E_UNSUPPORTED;
+    std::vector<RefLogEntry> log;
+    for (size_t i = 0; i < n; i++) {
+        Ray ray; to_ray(&ray, &rays[i]);
+        ShadeRec sr, tmp_sr;
+        float min_t = TMAX;
+        log.clear();
+        g_log = &log;
+        if (s->accel == CRT_ACCEL_BVH4) {
+            if (s->tree4) min_t = BVH4IntersectTest(&sr, s->tree4, ray);
+            for (int k = 0; k < s->num_non_grid; k++) {
+                float tmp_t = hook_rayIntersectObject(&tmp_sr, s->objects[k], ray);
+                if (tmp_t < min_t) min_t = tmp_t;
+            }
+        } else {
+            for (int k = 0; k < s->num_obj; k++) {
+                float tmp_t = hook_rayIntersectObject(&tmp_sr, s->objects[k], ray);
+                if (tmp_t < min_t) min_t = tmp_t;
+            }
+        }
+        g_log = 0;
+        crt_hit h; h.t = min_t; h.obj = -1; h.part = -1; h.beta = 0; h.gamma = 0;
+        if (min_t < TMAX) {
+            for (size_t k = 0; k < log.size(); k++) if (log[k].t == min_t) {
+                h.obj = s->id_of.at(log[k].ptr);
+                fill_details(s, log[k].ptr, ray, &h);
+                break;
+            }
+        }
+        hits[i] = h;
+    }
+    return 0;
+}
+
+/* n x { BVH4 / NONE branch of shadowIntersectTest (intersect.h:470-498) } */
+REF_API int ref_shadow(const ref_scene* s, const crt_ray* rays, const float* light_dist, size_t n,
+                       float* t_out, uint8_t* occluded_out)
+{
+    if (s->accel != CRT_ACCEL_BVH4 && s->accel != CRT_ACCEL_NONE) return CRT_E_UNSUPPORTED;
+    for (size_t i = 0; i < n; i++) {
+        Ray ray; to_ray(&ray, &rays[i]);
+        float ld = light_dist[i];
+        float t = TMAX;
+        if (s->accel == CRT_ACCEL_BVH4) {
+            if (s->tree4) t = BVH4ShadowIntersectTest(s->tree4, ray, ld);
+            if (t >= ld) {
+                for (int k = 0; k < s->num_non_grid; k++) {
+                    t = shadowRayIntersectObject(s->objects[k], ray);
+                    if (t < ld) break;
+                }
+            }
+        } else {
+            for (int k = 0; k < s->num_obj; k++) {
+                t = shadowRayIntersectObject(s->objects[k], ray);
+                if (t < ld) break;
+            }
+        }
+        if (t_out) t_out[i] = t;
+        if (occluded_out) occluded_out[i] = (t < ld - K_EPSILON) ? 1 : 0;
+    }
+    return 0;
+}
+
+REF_API float ref_intersect_object(const ref_scene* s, int final_index, const crt_ray* ray, crt_hit* hit)
+{
+    Ray r; to_ray(&r, ray);
+    ShadeRec sr;
+    float t = rayIntersectObject(&sr, s->objects[final_index], r);
+    if (hit) {
+        hit->t = t; hit->obj = s->id_of.at(s->objects[final_index].ptr);
+        fill_details(s, s->objects[final_index].ptr, r, hit);
+    }
+    return t;
+}
+REF_API float ref_shadow_object(const ref_scene* s, int final_index, const crt_ray* ray)
+{
+    Ray r; to_ray(&r, ray);
+    return shadowRayIntersectObject(s->objects[final_index], r);
+}
+REF_API float ref_ray_aabb(const float bmin[3], const float bmax[3], const crt_ray* ray)
+{
+    Ray r; to_ray(&r, ray);
+    AABB b;
+    vec3_assign(b.min, bmin[0], bmin[1], bmin[2]);
+    vec3_assign(b.max, bmax[0], bmax[1], bmax[2]);
+    return rayIntersectAABB(&b, r);
+}
+/* rayIntersectAABB4 (bvh4.h:23-97) on one node's 24 floats */
+REF_API void ref_ray_aabb4(const float bbox[24], const crt_ray* ray, float t_out[4], int32_t less_than_out[4])
+{
+    Ray r; to_ray(&r, ray);
+    CACHE_ALIGN float bb[24];
+    memcpy(bb, bbox, sizeof bb);
+    CACHE_ALIGN float res[4];
+    CACHE_ALIGN float lt[4];
+    __m128 tmp = rayIntersectAABB4((__m128*)lt, bb, r);
+    _mm_store_ps(res, tmp);
+    for (int i = 0; i < 4; i++) { t_out[i] = res[i]; less_than_out[i] = lt[i] ? 1 : 0; }
+}
+REF_API int ref_sizes(int* shaderec, int* node4, int* node2, int* object_t)
+{
+    *shaderec = (int)sizeof(ShadeRec); *node4 = (int)sizeof(BVHNode4); *node2 = (int)sizeof(BVHNode); *object_t = (int)sizeof(Object_t);
+    return 0;
+}
