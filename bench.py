@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- incoherent closest-hit throughput of the QBVH traversal kernel on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (n x intersectTest, /root/reference/intersect.h:365, BVH4
+branch) over one batch of 2^24 incoherent rays that is already resident in HBM.  The workload is
+BASELINE.json's headline configuration (configs[4]: "San Miguel ~10M tris, QBVH, incoherent diffuse
+bounces") on the procedural stand-in scenes.courtyard (the real asset is not shipped and cannot be
+fetched): 10 485 772 world-space triangles, QBVH built with the reference's rules, ray set
+R-incoherent = shuffled bounce-1..3 cosine-hemisphere rays.
+
+Multi-GPU: one process per GPU, full scene replica per GPU, each rank traces its own 2^24-ray batch
+(weak scaling, no data-path collective -- rays are independent); timing = max over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+WORKLOADS = {
+    # name: (n_copies, n_lat, n_lon) -> 2*n_lat*n_lon*n_copies + 12 triangles
+    "courtyard-10M": (640, 64, 128),
+    "courtyard-1M": (64, 64, 128),
+    "courtyard-64k": (4, 64, 128),
+}
+
+
+def gen_incoherent_rays(sc, si, n_rays, seed, device):
+    """R-incoherent on the GPU engine itself: random primary rays inside the scene bounds, then
+    cosine-hemisphere bounces from the hit points (origin = hit point, no offset), bounce 1..3,
+    shuffled.  Ray generation is input synthesis, outside the timed region."""
+    import torch
+    from craytracer_amd import api
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    tri = torch.from_numpy(si.tri_verts).to(device).view(-1, 3, 3)
+    lo = tri.view(-1, 3).min(0).values
+    hi = tri.view(-1, 3).max(0).values
+    n0 = int(n_rays / 3 * 1.15) + 1024
+    o = torch.rand((n0, 3), generator=g, device=device) * (hi - lo) + lo
+    d = torch.randn((n0, 3), generator=g, device=device)
+    d = d / d.norm(dim=1, keepdim=True)
+    rays = torch.cat([o, d], 1).float().contiguous()
+    out = []
+    for _ in range(3):
+        hits = torch.empty((rays.shape[0], 5), dtype=torch.int32, device=device)
+        sc.intersect_dev(rays.data_ptr(), rays.shape[0], hits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        obj = hits[:, 1].long()
+        ok = obj >= 0
+        t = hits[:, 0].view(torch.float32)
+        r = rays[ok]
+        tt = t[ok]
+        tv = tri[obj[ok]]
+        nrm = torch.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0], dim=1)
+        nrm = nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        flip = (nrm * r[:, 3:]).sum(1) > 0
+        nrm[flip] = -nrm[flip]
+        p = r[:, :3] + r[:, 3:] * tt[:, None]
+        u1 = torch.rand(r.shape[0], generator=g, device=device)
+        u2 = torch.rand(r.shape[0], generator=g, device=device)
+        rr, ph = u1.sqrt(), 2 * np.pi * u2
+        a = torch.where(nrm[:, :1].abs() > 0.9, torch.tensor([[0.0, 1.0, 0.0]], device=device),
+                        torch.tensor([[1.0, 0.0, 0.0]], device=device))
+        tx = torch.cross(a.expand_as(nrm), nrm, dim=1)
+        tx = tx / tx.norm(dim=1, keepdim=True)
+        ty = torch.cross(nrm, tx, dim=1)
+        dd = tx * (rr * ph.cos())[:, None] + ty * (rr * ph.sin())[:, None] + nrm * (1 - u1).clamp_min(0).sqrt()[:, None]
+        dd = dd / dd.norm(dim=1, keepdim=True)
+        rays = torch.cat([p, dd], 1).float().contiguous()
+        out.append(rays)
+    allr = torch.cat(out, 0)
+    perm = torch.randperm(allr.shape[0], generator=g, device=device)
+    allr = allr[perm]
+    if allr.shape[0] < n_rays:                      # top up with fresh random rays (rare: very open scenes)
+        extra = n_rays - allr.shape[0]
+        o = torch.rand((extra, 3), generator=g, device=device) * (hi - lo) + lo
+        d = torch.randn((extra, 3), generator=g, device=device)
+        allr = torch.cat([allr, torch.cat([o, d / d.norm(dim=1, keepdim=True)], 1).float()], 0)
+    return allr[:n_rays].contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="courtyard-10M", choices=sorted(WORKLOADS))
+    ap.add_argument("--rays", type=int, default=1 << 24)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from craytracer_amd import api, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the traversal path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    # ---- scene (full replica per GPU) ----
+    t0 = time.time()
+    n_copies, n_lat, n_lon = WORKLOADS[args.workload]
+    si = scenes.courtyard(n_copies, n_lat, n_lon, seed=5)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, local_rank)
+    build_s = time.time() - t0
+    n_tris = si.num_obj
+
+    # ---- rays: this rank's own batch, resident in HBM ----
+    n = args.rays
+    d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
+    d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # per-ray traversal statistics (defines the algorithmic bytes), outside the timed region
+    sc.enable_counters(True)
+    sc.reset_counters()
+    step()
+    cnt = sc.counters()
+    sc.enable_counters(False)
+    nodes_per_ray = cnt["nodes_visited"] / n
+    tris_per_ray = cnt["prims_tested"] / n
+    # 24 (ray in) + 20 (hit out) + 128 per QBVH node + 36 + 4 per triangle tested
+    bytes_per_ray = 24 + 20 + 128 * nodes_per_ray + 40 * tris_per_ray
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(sc.last_kernel_ms())      # HIP events on the launch stream (syncs the step)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
+
+    total_rays = float(n) * world * args.steps
+    value = total_rays / elapsed / 1e6
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    achieved_gbs = bytes_per_ray * n / (avg_kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Mrays/s closest-hit (incoherent), QBVH",
+        "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), QBVH, %d incoherent "
+                               "bounce-1..3 rays per GPU per step" % (args.workload, n_tris, n),
+                   "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "pruned",
+                   "parallelism": "scene replica per GPU, rays sharded, no collective", "hit_fraction": round(hit_frac, 4),
+                   "scene_build_s": round(build_s, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4),
+                     "bytes_per_ray": round(bytes_per_ray, 2), "nodes_per_ray": round(nodes_per_ray, 3),
+                     "tris_per_ray": round(tris_per_ray, 3)},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file)).get(args.workload)
+            if tr and tr.get("rays") == n:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU checker timed as "the reference's path on the host cores": same tree, same rays
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oraclelib as ol
+        o = ol.OracleScene(si, built=built)
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        host_rays = d_rays[: 1 << 20].cpu().numpy()
+        probe = host_rays[: 1 << 15]
+        t1 = time.perf_counter()
+        o.intersect(probe, mode=api.TRAVERSE_EXACT, nthreads=cores)
+        rate = len(probe) / max(time.perf_counter() - t1, 1e-6)
+        m = int(min(len(host_rays), max(len(probe), rate * args.cpu_seconds)))
+        sample = host_rays[:m]
+        t1 = time.perf_counter()
+        ref_hits = o.intersect(sample, mode=api.TRAVERSE_EXACT, nthreads=cores)
+        cpu_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        o.intersect(sample[: max(m // 8, 1)], mode=api.TRAVERSE_EXACT, nthreads=1)
+        cpu1_s = time.perf_counter() - t1
+        gpu_hits = d_hits[:m].cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
+        same = bool(ol.same_bits(gpu_hits, ref_hits))
+        out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "sample": "first %d rays of the GPU batch, oracle in the reference's control flow "
+                                         "(min_t local to each node), %.1f s" % (m, cpu_s),
+                               "one_thread_mrays": round(max(m // 8, 1) / cpu1_s / 1e6, 4),
+                               "gpu_bit_identical_on_sample": same}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

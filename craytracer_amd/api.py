@@ -100,6 +100,13 @@ def lib():
         raise RuntimeError(
             "craytracer_amd: %s is missing -- build it with `make -C craytracer_amd/csrc` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If the process
+    # is going to use torch as well, torch's copy must be the one that gets loaded (same soname,
+    # so libcrt_gpu.so then binds to it); loading /opt/rocm's first leaves torch without devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.crt_build_scene.argtypes = [C.POINTER(CrtSceneInput), C.c_int, C.POINTER(vp)]

@@ -1336,6 +1336,44 @@ oracle_scene* oracle_scene_create(const crt_scene_input* in, int accel, int sort
     return s;
 }
 
+/* Adopt an already built scene (final order + flat accelerator), e.g. the product builder's
+ * output, so that large scenes are traversed over the very same tree without rebuilding it. */
+oracle_scene* oracle_scene_from_desc(const crt_scene_desc* d)
+{
+    if (!d) return 0;
+    oracle_scene* s = new oracle_scene();
+    s->accel = d->accel;
+    s->num_non_grid = d->num_non_grid_obj;
+    s->tri.assign(d->tri_verts, d->tri_verts + (size_t)d->num_tris * 9);
+    if (d->num_shapes > 0) s->shapes.assign(d->shapes, d->shapes + d->num_shapes);
+    s->objects.resize(d->num_obj);
+    for (int i = 0; i < d->num_obj; i++) { s->objects[i].type = d->obj_type[i]; s->objects[i].ref = d->obj_ref[i]; s->objects[i].id = d->obj_id[i]; }
+    s->nodes4.resize(d->num_nodes4);
+    for (int i = 0; i < d->num_nodes4; i++) {
+        memcpy(s->nodes4[i].bbox, d->nodes4[i].bbox, sizeof(float) * 24);
+        for (int c = 0; c < 4; c++) { s->nodes4[i].child[c] = d->nodes4[i].child[c]; s->nodes4[i].type[c] = d->nodes4[i].type[c]; }
+        s->nodes4[i].axis = d->nodes4[i].axis;
+    }
+    s->nodes2.resize(d->num_nodes2);
+    for (int i = 0; i < d->num_nodes2; i++) {
+        ONode2& n = s->nodes2[i];
+        for (int k = 0; k < 3; k++) { n.aabb.min[k] = d->nodes2[i].bmin[k]; n.aabb.max[k] = d->nodes2[i].bmax[k]; }
+        n.leaf = d->nodes2[i].left < 0;
+        n.left = n.leaf ? -1 : d->nodes2[i].left;
+        n.right = n.leaf ? -1 : d->nodes2[i].right;
+        n.obj = n.leaf ? d->nodes2[i].right : -1;
+    }
+    if (d->accel == CRT_ACCEL_GRID) {
+        s->nx = d->grid.nx; s->ny = d->grid.ny; s->nz = d->grid.nz; s->num_cells = d->grid.num_cells;
+        s->wx = d->grid.wx; s->wy = d->grid.wy; s->wz = d->grid.wz;
+        for (int k = 0; k < 3; k++) { s->gaabb.min[k] = d->grid.bmin[k]; s->gaabb.max[k] = d->grid.bmax[k]; }
+        s->cells.assign(s->num_cells, std::vector<int>());
+        for (int c = 0; c < s->num_cells; c++)
+            s->cells[c].assign(d->cell_items + d->cell_start[c], d->cell_items + d->cell_start[c+1]);
+    }
+    return s;
+}
+
 void oracle_scene_destroy(oracle_scene* s) { delete s; }
 
 int oracle_scene_order(const oracle_scene* s, int32_t* ids, int32_t* num_non_grid)

@@ -29,6 +29,8 @@ typedef struct oracle_scene oracle_scene;
  * range (deterministic; what the product's builder does), 1 = the reference's own
  * insertion-sort / rand()-pivot quicksort (bvh.h:56-112), for comparison with oracle/_ref. */
 oracle_scene* oracle_scene_create(const crt_scene_input* in, int accel, int sort_mode);
+/* Adopt an already built scene (final order + flat accelerator) without rebuilding it. */
+oracle_scene* oracle_scene_from_desc(const crt_scene_desc* d);
 void          oracle_scene_destroy(oracle_scene* s);
 
 /* Final objects[] order as insertion ids; returns num_obj.  ids may be NULL. */

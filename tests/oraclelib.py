@@ -23,6 +23,8 @@ def oracle():
         L = C.CDLL(ORACLE_PATH)
         L.oracle_scene_create.argtypes = [C.POINTER(api.CrtSceneInput), C.c_int, C.c_int]
         L.oracle_scene_create.restype = vp
+        L.oracle_scene_from_desc.argtypes = [C.POINTER(api.CrtSceneDesc)]
+        L.oracle_scene_from_desc.restype = vp
         L.oracle_scene_destroy.argtypes = [vp]
         L.oracle_scene_destroy.restype = None
         L.oracle_scene_order.argtypes = [vp, vp, C.POINTER(C.c_int32)]
@@ -108,12 +110,16 @@ class _SceneBase:
 
 
 class OracleScene(_SceneBase):
-    def __init__(self, scene_input, accel, sort_mode=0):
+    def __init__(self, scene_input, accel=None, sort_mode=0, built=None):
+        """built: an api.BuiltScene to adopt (same tree as the GPU) instead of building from input."""
         L = oracle()
         self.L = L
         self.input = scene_input
-        cin = scene_input.c_struct()
-        self.h = L.oracle_scene_create(C.byref(cin), int(accel), int(sort_mode))
+        if built is not None:
+            self.h = L.oracle_scene_from_desc(C.byref(built.desc))
+        else:
+            cin = scene_input.c_struct()
+            self.h = L.oracle_scene_create(C.byref(cin), int(accel), int(sort_mode))
         assert self.h
         self.L_order, self.L_nodes4, self.L_nodes2, self.L_grid = \
             L.oracle_scene_order, L.oracle_scene_nodes4, L.oracle_scene_nodes2, L.oracle_scene_grid

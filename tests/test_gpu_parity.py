@@ -1,0 +1,196 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded rays.
+
+Bar (BASELINE.json north_star): hit ids (obj, part) bit-exact, t / beta / gamma within 1e-5
+relative (absolute 1e-5 when |x| < 1).  Triangle scenes are additionally required to be
+bit-identical in t, beta, gamma -- the arithmetic is libm-free and contraction is off on both sides.
+Analytic shapes go through device atan2f/acosf/cbrt/cos, which differ from glibc in the last ulp
+(near-tie class T4): ids may differ only on rays whose oracle hit sits on a window seam,
+and such rays are counted and bounded, not ignored.
+"""
+import numpy as np
+import pytest
+
+from craytracer_amd import api, scenes
+import oraclelib as ol
+
+pytestmark = pytest.mark.gpu
+
+ACCELS = [api.ACCEL_NONE, api.ACCEL_GRID, api.ACCEL_BVH, api.ACCEL_BVH4]
+TOL = 1e-5
+
+
+def close(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    scale = np.maximum(1.0, np.abs(b))
+    both_nan = np.isnan(a) & np.isnan(b)
+    return both_nan | (np.abs(a - b) <= TOL * scale) | (a == b)
+
+
+def rayset(si, n=8192, seed=5):
+    lo, hi = scenes.scene_bounds(si)
+    pad = (hi - lo) * 0.2
+    r = scenes.random_rays(n, lo - pad, hi + pad, seed)
+    ld = (np.random.default_rng(seed).random(n) * np.linalg.norm(hi - lo)).astype(np.float32)
+    return r, ld
+
+
+def run_pair(si, accel, rays, ld, mode=api.TRAVERSE_AUTO):
+    built = api.BuiltScene(si, accel)
+    sc = api.Scene(built, 0)
+    sc.set_traverse_mode(mode)
+    resolved = sc.traverse_mode()
+    o = ol.OracleScene(si, accel, sort_mode=0)
+    g_hits = sc.intersect(rays)
+    g_t, g_occ = sc.shadow(rays, ld)
+    o_hits = o.intersect(rays, mode=api.TRAVERSE_EXACT)
+    o_t, o_occ = o.shadow(rays, ld)
+    sc.close()
+    return g_hits, g_t, g_occ, o_hits, o_t, o_occ, resolved
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("scene", ["rand2k", "blobs", "cornell"])
+def test_triangle_scenes_bit_exact(scene, accel):
+    if scene == "rand2k":
+        si = scenes.random_tris(2000, seed=3)
+    elif scene == "blobs":
+        si = scenes.courtyard(4, 16, 32, seed=9)
+    else:
+        c = scenes.cornell29()
+        keep = c.obj_type == api.TRIANGLE                     # triangle part of S1
+        si = api.SceneInput(c.tri_verts)
+        assert keep.sum() == 20
+    rays, ld = rayset(si)
+    g_hits, g_t, g_occ, o_hits, o_t, o_occ, mode = run_pair(si, accel, rays, ld)
+    if accel in (api.ACCEL_BVH, api.ACCEL_BVH4):
+        assert mode == api.TRAVERSE_PRUNED
+    assert (o_hits["obj"] >= 0).sum() > 100
+    assert np.array_equal(g_hits["obj"], o_hits["obj"])
+    assert np.array_equal(g_hits["part"], o_hits["part"])
+    assert ol.same_bits(g_hits["t"], o_hits["t"])
+    assert ol.same_bits(g_hits["beta"], o_hits["beta"]) and ol.same_bits(g_hits["gamma"], o_hits["gamma"])
+    assert ol.same_bits(g_t, o_t)
+    assert np.array_equal(g_occ, o_occ)
+
+
+@pytest.mark.parametrize("accel", [api.ACCEL_BVH, api.ACCEL_BVH4])
+def test_exact_mode_equals_pruned_on_triangles(accel):
+    si = scenes.random_tris(3000, seed=8)
+    rays, ld = rayset(si, 4096, 2)
+    a = run_pair(si, accel, rays, ld, api.TRAVERSE_EXACT)
+    b = run_pair(si, accel, rays, ld, api.TRAVERSE_PRUNED)
+    assert a[6] == api.TRAVERSE_EXACT and b[6] == api.TRAVERSE_PRUNED
+    for k in range(3):
+        assert ol.same_bits(a[k], b[k])
+    assert ol.same_bits(a[0], a[3])
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("scene", ["cornell29", "analytic", "analytic_unrotated"])
+def test_mixed_scenes(scene, accel):
+    si = {"cornell29": scenes.cornell29, "analytic": scenes.analytic_scene,
+          "analytic_unrotated": lambda: scenes.analytic_scene(False)}[scene]()
+    lo, hi = (np.array([-7, -2, -7], np.float32), np.array([7, 5, 7], np.float32)) if scene != "cornell29" \
+        else (np.array([-50, -50, -600], np.float32), np.array([600, 600, 50], np.float32))
+    rays = scenes.random_rays(8192, lo, hi, 21)
+    ld = (np.random.default_rng(4).random(len(rays)) * np.linalg.norm(hi - lo)).astype(np.float32)
+    g_hits, g_t, g_occ, o_hits, o_t, o_occ, mode = run_pair(si, accel, rays, ld)
+    if scene != "cornell29" and accel in (api.ACCEL_BVH, api.ACCEL_BVH4):
+        assert mode == api.TRAVERSE_EXACT
+    same_id = (g_hits["obj"] == o_hits["obj"]) & (g_hits["part"] == o_hits["part"])
+    ok_t = close(g_hits["t"], o_hits["t"])
+    bad = ~(same_id & ok_t)
+    # libm last-ulp class (T4): only scenes with sphere / cylinder / torus may show any, and few
+    limit = 0 if scene == "cornell29" else 8
+    assert bad.sum() <= limit, (bad.sum(), g_hits[bad][:5], o_hits[bad][:5])
+    good = ~bad
+    assert close(g_hits["beta"][good], o_hits["beta"][good]).all()
+    assert close(g_hits["gamma"][good], o_hits["gamma"][good]).all()
+    bad_s = ~close(g_t, o_t)
+    assert bad_s.sum() <= limit, (bad_s.sum(), g_t[bad_s][:5], o_t[bad_s][:5])
+    assert (g_occ != o_occ).sum() <= limit
+    if scene == "cornell29":
+        assert ol.same_bits(g_hits["t"], o_hits["t"]) and ol.same_bits(g_t, o_t)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_axis_parallel_and_negative_zero_rays(accel):
+    """classes T2 / T3: zero and -0.0 direction components follow the reference's inf/NaN flow."""
+    si = scenes.random_tris(1500, seed=12)
+    lo, hi = scenes.scene_bounds(si)
+    rays = scenes.axis_parallel_rays(4096, lo, hi)
+    ld = np.full(len(rays), 0.7, np.float32)
+    g_hits, g_t, g_occ, o_hits, o_t, o_occ, _ = run_pair(si, accel, rays, ld)
+    assert np.array_equal(g_hits["obj"], o_hits["obj"])
+    assert ol.same_bits(g_hits["t"], o_hits["t"])
+    assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
+
+
+def test_empty_and_ragged_batches():
+    si = scenes.random_tris(100, seed=1)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, 0)
+    o = ol.OracleScene(si, api.ACCEL_BVH4)
+    assert len(sc.intersect(np.zeros((0, 6), np.float32))) == 0
+    for n in (1, 63, 64, 65, 257, 1000):
+        rays = scenes.random_rays(n, [0, 0, 0], [1, 1, 1], n)
+        assert ol.same_bits(sc.intersect(rays), o.intersect(rays))
+    sc.close()
+
+
+def test_tiny_scenes():
+    """1..6 objects: nodes with empty (inverted-box) children, root leaf for the binary BVH."""
+    for n in (1, 2, 3, 4, 5, 6):
+        si = scenes.random_tris(n, seed=n, size=0.4)
+        rays = scenes.random_rays(2048, [-0.5] * 3, [1.5] * 3, 3)
+        ld = np.full(len(rays), 1.0, np.float32)
+        for accel in ACCELS:
+            g_hits, g_t, g_occ, o_hits, o_t, o_occ, _ = run_pair(si, accel, rays, ld)
+            assert ol.same_bits(g_hits, o_hits), (n, accel)
+            assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
+
+
+def test_counters_match_oracle_pruned_traversal():
+    si = scenes.courtyard(4, 16, 32, seed=2)
+    rays, ld = rayset(si, 4096, 9)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, 0)
+    sc.enable_counters(True)
+    sc.reset_counters()
+    sc.intersect(rays)
+    c = sc.counters()
+    o = ol.OracleScene(si, api.ACCEL_BVH4)
+    _, oc = o.intersect(rays, mode=api.TRAVERSE_PRUNED, counters=True)
+    assert c["rays_closest"] == len(rays)
+    assert c["nodes_visited"] == oc["nodes_visited"]
+    assert c["prims_tested"] == oc["prims_tested"]
+    sc.close()
+
+
+def test_device_pointer_entry_points_and_timer():
+    import torch
+    si = scenes.random_tris(5000, seed=6)
+    rays, ld = rayset(si, 10000, 1)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, 0)
+    o = ol.OracleScene(si, api.ACCEL_BVH4)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty(len(rays) * 5, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    sc.intersect_dev(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), st.cuda_stream)
+    ms = sc.last_kernel_ms()
+    st.synchronize()
+    assert ms > 0
+    got = d_hits.cpu().numpy().view(api.HIT_DTYPE)
+    assert ol.same_bits(got, o.intersect(rays))
+    d_ld = torch.from_numpy(ld).cuda()
+    d_t = torch.empty(len(rays), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(len(rays), dtype=torch.uint8, device="cuda")
+    sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), len(rays), d_t.data_ptr(), d_occ.data_ptr(), None)
+    torch.cuda.synchronize()
+    o_t, o_occ = o.shadow(rays, ld)
+    assert ol.same_bits(d_t.cpu().numpy(), o_t)
+    assert np.array_equal(d_occ.cpu().numpy().astype(bool), o_occ)
+    sc.close()
