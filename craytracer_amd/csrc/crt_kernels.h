@@ -139,6 +139,32 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
     return t;
 }
 
+/* ---- lane refill -------------------------------------------------------------------
+ * Incoherent rays visit very different numbers of nodes (the tail is several times the mean),
+ * so a wave that waits for the slowest of 64 rays runs with most lanes switched off (measured:
+ * 12 % active lanes per VALU instruction, profiles/r01_pmc_baseline.txt).  Instead, lanes whose
+ * ray has finished are refilled from the queue while the others keep walking: once at least
+ * CRT_REFILL_MIN lanes are idle, one agent-scope atomic claims that many rays for the wave, and
+ * each idle lane takes the claimed slot given by its rank among the idle lanes (ballot + mbcnt). */
+#define CRT_REFILL_MIN 16
+
+CRT_DEV unsigned lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+/* Returns this lane's new ray index (or 0xFFFFFFFF); *queue_empty is wave-uniform. */
+CRT_DEV unsigned refill(unsigned* queue_head, unsigned n, unsigned long long idle, bool lane_idle, bool* queue_empty)
+{
+    const unsigned cnt = (unsigned)__popcll(idle);
+    unsigned base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(queue_head, cnt);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + cnt >= n) *queue_empty = true;
+    if (!lane_idle) return 0xFFFFFFFFu;
+    const unsigned idx = base + lane_rank(idle);
+    return idx < n ? idx : 0xFFFFFFFFu;
+}
+
 /* =====================================================================================
  * QBVH closest hit, best-t pruned, reference child order.
  * BVH4IntersectTest (accelerator/bvh4.h:299-389) + the BVH4 branch of intersectTest
@@ -153,7 +179,6 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
 {
     __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
     __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
-    const unsigned lane = threadIdx.x & 63;
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
     st.lds_word = &s_word[0][threadIdx.x];
@@ -161,23 +186,39 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
+    st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
 
+    bool alive = false, queue_empty = false;
+    unsigned ri = 0, cur = 0;
+    DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
+    float ia = 1.0f, ib = 1.0f, ic = 1.0f;
+    bool sx = true, sy = true, sz = true, px = true, walking = false;
+    float best_t = CRT_TMAX;
+    DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
-        if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
-            const DRay ray = load_ray(la.rays, ri);
-            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;   /* bvh4.h:26-28 */
-            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f; /* bvh4.h:43,:54,:65 */
-            const bool px = ray.dx > 0.0f;                                             /* bvh4.h:312 (axis0 = axis1 = 0) */
-            float best_t = CRT_TMAX;
-            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
-            st.sp = 0;
-            bool alive = sc.n_accel > 0;
-            unsigned cur = 0;                              /* root */
-            while (alive) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
+            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
+            if (idx != 0xFFFFFFFFu) {
+                ri = idx;
+                ray = load_ray(la.rays, ri);
+                ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
+                sx = ray.dx >= 0.0f; sy = ray.dy >= 0.0f; sz = ray.dz >= 0.0f;        /* bvh4.h:43,:54,:65 */
+                px = ray.dx > 0.0f;                                                    /* bvh4.h:312 (axis0 = axis1 = 0) */
+                best_t = CRT_TMAX;
+                best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+                st.sp = 0;
+                cur = 0;                                                               /* root */
+                walking = sc.n_accel > 0;
+                alive = true;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
+        if (alive) {
+            if (walking) {
+                bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
                     const float4* nd = sc.nodes4 + (size_t)cur * 8;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
@@ -206,7 +247,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     if (s3k < best_t) st.push(s3w, s3k);
                     if (s2k < best_t) st.push(s2w, s2k);
                     if (s1k < best_t) st.push(s1w, s1k);
-                    if (s0k < best_t) { cur = s0w; continue; }
+                    if (s0k < best_t) { cur = s0w; need_pop = false; }
                 } else {
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
@@ -217,16 +258,21 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                         if (t < best_t) { best_t = t; best = h; }
                     }
                 }
-                alive = false;
-                while (st.sp > 0) {
-                    unsigned w; float key;
-                    st.pop(&w, &key);
-                    if (key < best_t) { cur = w; alive = true; break; }
+                if (need_pop) {
+                    walking = false;
+                    while (st.sp > 0) {
+                        unsigned w; float key;
+                        st.pop(&w, &key);
+                        if (key < best_t) { cur = w; walking = true; break; }
+                    }
                 }
             }
-            linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-            store_hit(la.hits, ri, best_t, best);
-            if (COUNT) c_rays++;
+            if (!walking) {
+                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                store_hit(la.hits, ri, best_t, best);
+                if (COUNT) c_rays++;
+                alive = false;
+            }
         }
     }
     flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, false);
@@ -242,7 +288,6 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
 {
     __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
     __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
-    const unsigned lane = threadIdx.x & 63;
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
     st.lds_word = &s_word[0][threadIdx.x];
@@ -250,23 +295,37 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
+    st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
 
+    bool alive = false, queue_empty = false;
+    unsigned ri = 0, cur = 0;
+    DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
+    float ia = 1.0f, ib = 1.0f, ic = 1.0f, ld = 0.0f, result = CRT_TMAX;
+    bool sx = true, sy = true, sz = true, px = true, walking = false;
+
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
-        if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
-            const DRay ray = load_ray(la.rays, ri);
-            const float ld = la.light_dist[ri];
-            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;
-            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
-            const bool px = ray.dx > 0.0f;
-            float result = CRT_TMAX;
-            st.sp = 0;
-            bool alive = sc.n_accel > 0;
-            unsigned cur = 0;
-            while (alive) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
+            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
+            if (idx != 0xFFFFFFFFu) {
+                ri = idx;
+                ray = load_ray(la.rays, ri);
+                ld = la.light_dist[ri];
+                ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;
+                sx = ray.dx >= 0.0f; sy = ray.dy >= 0.0f; sz = ray.dz >= 0.0f;
+                px = ray.dx > 0.0f;
+                result = CRT_TMAX;
+                st.sp = 0;
+                cur = 0;
+                walking = sc.n_accel > 0;
+                alive = true;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive) {
+            if (walking) {
+                bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
                     const float4* nd = sc.nodes4 + (size_t)cur * 8;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
@@ -292,27 +351,30 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                     if (s3v) st.push(s3w, 0.0f);
                     if (s2v) st.push(s2w, 0.0f);
                     if (s1v) st.push(s1w, 0.0f);
-                    if (s0v) { cur = s0w; continue; }
+                    if (s0v) { cur = s0w; need_pop = false; }
                 } else {
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
-                    bool found = false;
                     for (int j = 0; j < count; j++) {                                 /* bvh4.h:464-472 */
                         DHit h;
                         const float t = dev_object<TRI_ONLY>(sc, first + j, ray, true, &h);
                         if (COUNT) c_prims++;
-                        if (t < ld) { result = t; found = true; break; }
+                        if (t < ld) { result = t; walking = false; need_pop = false; break; }
                     }
-                    if (found) break;
                 }
-                if (st.sp > 0) { float key; st.pop(&cur, &key); }
-                else alive = false;
+                if (need_pop) {
+                    if (st.sp > 0) { float key; st.pop(&cur, &key); }
+                    else walking = false;
+                }
             }
-            if (result >= ld)                                                          /* intersect.h:474 */
-                result = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, result, &c_prims);
-            if (la.t_out) la.t_out[ri] = result;
-            if (la.occ_out) la.occ_out[ri] = (result < ld - CRT_K_EPSILON) ? 1 : 0;   /* trace.h:348 */
-            if (COUNT) c_rays++;
+            if (!walking) {
+                if (result >= ld)                                                      /* intersect.h:474 */
+                    result = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, result, &c_prims);
+                if (la.t_out) la.t_out[ri] = result;
+                if (la.occ_out) la.occ_out[ri] = (result < ld - CRT_K_EPSILON) ? 1 : 0;   /* trace.h:348 */
+                if (COUNT) c_rays++;
+                alive = false;
+            }
         }
     }
     flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, true);

@@ -1001,6 +1001,44 @@ void bvh4Pruned(const oracle_scene* s, int ni, const Ray& ray, float* min_t, Hit
     }
 }
 
+/* Nearest-first variant of the pruned walk (children of a node visited by ascending box key,
+ * origin-inside children first; ties between children keep the reference's order).  Same min t;
+ * *tie is set when a second object reaches exactly the best t, in which case the caller falls
+ * back to the reference order to name the winner. */
+void bvh4Nearest(const oracle_scene* s, int ni, const Ray& ray, float* min_t, HitInfo* sr, bool* tie, Counters* cn)
+{
+    const ONode4& nd = s->nodes4[ni];
+    float bbox_result[4]; bool less_than[4]; int indices[4];
+    cn->nodes++;
+    rayAABB4(nd.bbox, ray, bbox_result, less_than);
+    childOrder(nd, ray, indices);
+    float key[4]; int ord[4];
+    for (int i = 0; i < 4; i++) {
+        int index = indices[i];
+        key[i] = (less_than[index] && bbox_result[index] < TMAX) ? -INFINITY : bbox_result[index];
+        ord[i] = index;
+    }
+    for (int i = 1; i < 4; i++)                       /* stable insertion sort by key */
+        for (int j = i; j > 0 && key[j-1] > key[j]; --j) { std::swap(key[j-1], key[j]); std::swap(ord[j-1], ord[j]); }
+    for (int i = 0; i < 4; i++) {
+        int index = ord[i];
+        if (key[i] < *min_t) {
+            if (nd.type[index] == -1) {
+                bvh4Nearest(s, nd.child[index], ray, min_t, sr, tie, cn);
+            } else {
+                for (int j = 0; j < nd.type[index]; j++) {
+                    int oi = nd.child[index] + j;
+                    HitInfo tmp_sr;
+                    cn->prims++;
+                    float t = objIntersect(s, s->objects[oi], ray, &tmp_sr);
+                    if (t < *min_t) { *min_t = t; tmp_sr.obj = oi; *sr = tmp_sr; *tie = false; }
+                    else if (t == *min_t && t < TMAX) *tie = true;
+                }
+            }
+        }
+    }
+}
+
 /* BVH4ShadowIntersectTest, bvh4.h:392-478 */
 float bvh4Shadow(const oracle_scene* s, int ni, const Ray& ray, float light_dist, Counters* cn)
 {
@@ -1233,7 +1271,12 @@ float intersectTest(const oracle_scene* s, const Ray& ray, HitInfo* sr, int mode
                 }
             }
         } else if (n_accel > 0) {
-            if (mode == CRT_TRAVERSE_PRUNED) bvh4Pruned(s, 0, ray, &min_t, sr, cn);
+            if (mode == 3) {                       /* experimental: nearest-first with tie fallback */
+                bool tie = false;
+                bvh4Nearest(s, 0, ray, &min_t, sr, &tie, cn);
+                if (tie) { min_t = TMAX; bvh4Pruned(s, 0, ray, &min_t, sr, cn); }
+            }
+            else if (mode == CRT_TRAVERSE_PRUNED) bvh4Pruned(s, 0, ray, &min_t, sr, cn);
             else { HitInfo h; h.obj = -1; h.part = -1; h.beta = h.gamma = 0;
                    min_t = bvh4Exact(s, 0, ray, &h, cn); if (min_t < TMAX) *sr = h; }
         }
