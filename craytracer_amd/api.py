@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcrt_gpu.so")
+LIB_PATH = os.environ.get("CRT_GPU_LIB") or os.path.join(_HERE, "csrc", "libcrt_gpu.so")   # CRT_GPU_LIB: experiment builds
 
 # enums (include/crt_gpu.h; same values as shapes/objecttype.h:4-18 and scene/scenedata.h:12-18)
 SPHERE, PLANE, RECTANGLE, AABOX, TRIANGLE, GENERICOPENCYLINDER, DISK, GENERICTORUS, INSTANCED, COMPOUND, \

@@ -32,20 +32,36 @@ struct LaunchArgs {
     unsigned grid_threads;
 };
 
-/* ---- per-lane stack ---------------------------------------------------------------- */
+/* ---- per-lane stack ----------------------------------------------------------------
+ * Entry = (child word, key) packed in 8 bytes -> one ds_write_b64 / ds_read_b64.  The LDS part is
+ * addressed through the __shared__ array itself so that every access is a DS instruction; the
+ * overflow part is kept out of line (a pointer select between the two would turn every pop into
+ * a flat load that waits on both memory counters). */
+typedef uint2 StackEntry;
+
+__device__ __noinline__ void ovf_push(unsigned* ovf_word, float* ovf_key, size_t o, unsigned w, float key)
+{
+    ovf_word[o] = w; ovf_key[o] = key;
+}
+__device__ __noinline__ StackEntry ovf_pop(const unsigned* ovf_word, const float* ovf_key, size_t o)
+{
+    StackEntry e; e.x = ovf_word[o]; e.y = __float_as_uint(ovf_key[o]);
+    return e;
+}
+
 struct LaneStack {
-    unsigned* lds_word;           /* &s_word[0][tid] */
-    float* lds_key;               /* &s_key[0][tid]  */
+    StackEntry (*lds)[CRT_BLOCK];   /* the workgroup's __shared__ [CRT_LDS_DEPTH][CRT_BLOCK] array */
     unsigned* ovf_word;           /* &ovf_word[0][gtid] */
     float* ovf_key;
     unsigned ovf_stride;
     int sp;
     CRT_DEV void push(unsigned w, float key)
     {
-        if (sp < CRT_LDS_DEPTH) { lds_word[sp * CRT_BLOCK] = w; lds_key[sp * CRT_BLOCK] = key; }
-        else if (sp < CRT_STACK_MAX) {
-            size_t o = (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride;
-            ovf_word[o] = w; ovf_key[o] = key;
+        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) {
+            StackEntry e; e.x = w; e.y = __float_as_uint(key);
+            lds[sp][threadIdx.x] = e;
+        } else if (sp < CRT_STACK_MAX) {
+            ovf_push(ovf_word, ovf_key, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride, w, key);
         }
         /* deeper than CRT_STACK_MAX cannot happen: crt_scene_create rejects such trees */
         sp++;
@@ -53,11 +69,10 @@ struct LaneStack {
     CRT_DEV void pop(unsigned* w, float* key)
     {
         sp--;
-        if (sp < CRT_LDS_DEPTH) { *w = lds_word[sp * CRT_BLOCK]; *key = lds_key[sp * CRT_BLOCK]; }
-        else {
-            size_t o = (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride;
-            *w = ovf_word[o]; *key = ovf_key[o];
-        }
+        StackEntry e;
+        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) e = lds[sp][threadIdx.x];
+        else e = ovf_pop(ovf_word, ovf_key, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride);
+        *w = e.x; *key = __uint_as_float(e.y);
     }
 };
 
@@ -146,7 +161,12 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
  * ray has finished are refilled from the queue while the others keep walking: once at least
  * CRT_REFILL_MIN lanes are idle, one agent-scope atomic claims that many rays for the wave, and
  * each idle lane takes the claimed slot given by its rank among the idle lanes (ballot + mbcnt). */
+#ifndef CRT_REFILL_MIN
 #define CRT_REFILL_MIN 16
+#endif
+#ifndef CRT_TRI_STEP
+#define CRT_TRI_STEP 1
+#endif
 
 CRT_DEV unsigned lane_rank(unsigned long long mask)
 {
@@ -177,12 +197,10 @@ CRT_DEV unsigned refill(unsigned* queue_head, unsigned n, unsigned long long idl
 template <bool TRI_ONLY, bool COUNT>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
-    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
-    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
-    st.lds_word = &s_word[0][threadIdx.x];
-    st.lds_key = &s_key[0][threadIdx.x];
+    st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
@@ -251,12 +269,24 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                 } else {
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
+#if CRT_TRI_STEP
+                    /* one object of the leaf per step, in array order (bvh4.h:374-383): lanes that sit
+                     * in leaves of different sizes stay in step with the lanes that test boxes */
+                    if (count > 0) {
+                        DHit h;
+                        const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
+                        if (COUNT) c_prims++;
+                        if (t < best_t) { best_t = t; best = h; }
+                    }
+                    if (count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
+#else
                     for (int j = 0; j < count; j++) {                                 /* bvh4.h:374-383 */
                         DHit h;
                         const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
                         if (COUNT) c_prims++;
                         if (t < best_t) { best_t = t; best = h; }
                     }
+#endif
                 }
                 if (need_pop) {
                     walking = false;
@@ -286,12 +316,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
 template <bool TRI_ONLY, bool COUNT>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchArgs la)
 {
-    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
-    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
-    st.lds_word = &s_word[0][threadIdx.x];
-    st.lds_key = &s_key[0][threadIdx.x];
+    st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
@@ -435,13 +463,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
 template <bool TRI_ONLY, bool COUNT, bool SHADOW>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
-    __shared__ unsigned s_word[CRT_LDS_DEPTH][CRT_BLOCK];
-    __shared__ float s_key[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned lane = threadIdx.x & 63;
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
-    st.lds_word = &s_word[0][threadIdx.x];
-    st.lds_key = &s_key[0][threadIdx.x];
+    st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
