@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--presort", default="none", choices=["none", "morton", "morton_oct"],
+                    help="EXPERIMENT ONLY: reorder the input rays before the timed region")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +132,22 @@ def main():
     # ---- rays: this rank's own batch, resident in HBM ----
     n = args.rays
     d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
+    if args.presort != "none":
+        lo = d_rays[:, :3].min(0).values
+        hi = d_rays[:, :3].max(0).values
+        q = ((d_rays[:, :3] - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).long().clamp(0, 1023)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            v = (v | (v << 2)) & 0x09249249
+            return v
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        if args.presort == "morton_oct":
+            octant = (d_rays[:, 3] > 0).long() | ((d_rays[:, 4] > 0).long() << 1) | ((d_rays[:, 5] > 0).long() << 2)
+            key = (key >> 9 << 12) | (octant << 9) | (key & 0x1FF)
+        d_rays = d_rays[torch.argsort(key)].contiguous()
     d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
