@@ -101,12 +101,10 @@ def main():
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--presort", default="none", choices=["none", "morton", "morton_oct"],
-                    help="EXPERIMENT ONLY: reorder the input rays before the timed region")
     args = ap.parse_args()
 
     import torch
-    from craytracer_amd import api, scenes
+    from craytracer_amd import api, scenes, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -132,22 +130,6 @@ def main():
     # ---- rays: this rank's own batch, resident in HBM ----
     n = args.rays
     d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
-    if args.presort != "none":
-        lo = d_rays[:, :3].min(0).values
-        hi = d_rays[:, :3].max(0).values
-        q = ((d_rays[:, :3] - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).long().clamp(0, 1023)
-
-        def spread(v):
-            v = (v | (v << 16)) & 0x030000FF
-            v = (v | (v << 8)) & 0x0300F00F
-            v = (v | (v << 4)) & 0x030C30C3
-            v = (v | (v << 2)) & 0x09249249
-            return v
-        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-        if args.presort == "morton_oct":
-            octant = (d_rays[:, 3] > 0).long() | ((d_rays[:, 4] > 0).long() << 1) | ((d_rays[:, 5] > 0).long() << 2)
-            key = (key >> 9 << 12) | (octant << 9) | (key & 0x1FF)
-        d_rays = d_rays[torch.argsort(key)].contiguous()
     d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -181,10 +163,7 @@ def main():
         kernel_ms.append(sc.last_kernel_ms())      # HIP events on the launch stream (syncs the step)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = shard.max_over_ranks(elapsed, device)
     hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
 
     total_rays = float(n) * world * args.steps
@@ -223,8 +202,8 @@ def main():
         import oraclelib as ol
         o = ol.OracleScene(si, built=built)
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        host_rays = d_rays[: 1 << 20].cpu().numpy()
-        probe = host_rays[: 1 << 15]
+        host_rays = d_rays.cpu().numpy()
+        probe = host_rays[: 1 << 16]
         t1 = time.perf_counter()
         o.intersect(probe, mode=api.TRAVERSE_EXACT, nthreads=cores)
         rate = len(probe) / max(time.perf_counter() - t1, 1e-6)
@@ -233,15 +212,16 @@ def main():
         t1 = time.perf_counter()
         ref_hits = o.intersect(sample, mode=api.TRAVERSE_EXACT, nthreads=cores)
         cpu_s = time.perf_counter() - t1
+        m1 = max(m // (2 * cores), 1)
         t1 = time.perf_counter()
-        o.intersect(sample[: max(m // 8, 1)], mode=api.TRAVERSE_EXACT, nthreads=1)
+        o.intersect(sample[:m1], mode=api.TRAVERSE_EXACT, nthreads=1)
         cpu1_s = time.perf_counter() - t1
         gpu_hits = d_hits[:m].cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
         same = bool(ol.same_bits(gpu_hits, ref_hits))
         out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                "sample": "first %d rays of the GPU batch, oracle in the reference's control flow "
                                          "(min_t local to each node), %.1f s" % (m, cpu_s),
-                               "one_thread_mrays": round(max(m // 8, 1) / cpu1_s / 1e6, 4),
+                               "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4),
                                "gpu_bit_identical_on_sample": same}
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -13,7 +13,9 @@
 #include "crt_device.h"
 
 #define CRT_BLOCK      256
+#ifndef CRT_LDS_DEPTH
 #define CRT_LDS_DEPTH  16
+#endif
 #define CRT_OVF_DEPTH  32
 #define CRT_STACK_MAX  (CRT_LDS_DEPTH + CRT_OVF_DEPTH)
 #define CRT_EXACT4_DEPTH 16     /* QBVH levels the EXACT kernel's frame stack holds */
