@@ -170,6 +170,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     elapsed = shard.max_over_ranks(elapsed, device)
     hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
+    checksum = int(d_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF      # same scene + rays => same number
 
     total_rays = float(n) * world * args.steps
     value = total_rays / elapsed / 1e6
@@ -184,7 +185,7 @@ def main():
         "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), QBVH, %d incoherent "
                                "bounce-1..3 rays per GPU per step" % (args.workload, n_tris, n),
                    "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "pruned",
-                   "parallelism": "scene replica per GPU, rays sharded, no collective", "hit_fraction": round(hit_frac, 4),
+                   "parallelism": "scene replica per GPU, rays sharded, no collective", "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
                    "scene_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,

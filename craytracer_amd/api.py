@@ -83,6 +83,7 @@ EXPORTS = [
     "crt_build_scene", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode",
+    "crt_host_alloc", "crt_host_free",
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_strerror", "crt_last_hip_error",
@@ -120,6 +121,9 @@ def lib():
     L.crt_scene_destroy.restype = None
     L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
     L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.crt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.crt_host_free.argtypes = [vp]
+    L.crt_host_free.restype = None
     L.crt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
     L.crt_shadow_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.crt_intersect_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
@@ -154,6 +158,31 @@ def _check(code, where):
 
 def _ptr(a):
     return a.ctypes.data if a is not None and a.size else None
+
+
+class HostBuffer:
+    """Page-locked host array from crt_host_alloc, viewed as numpy (`.array`); free with close()."""
+
+    def __init__(self, shape, dtype):
+        self._dtype = np.dtype(dtype)
+        self._shape = tuple(np.atleast_1d(shape))
+        nbytes = int(np.prod(self._shape)) * self._dtype.itemsize
+        self._p = C.c_void_p()
+        _check(lib().crt_host_alloc(nbytes, C.byref(self._p)), "crt_host_alloc")
+        buf = (C.c_char * max(nbytes, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self._dtype, count=int(np.prod(self._shape))).reshape(self._shape)
+
+    def close(self):
+        if self._p is not None and self._p.value:
+            self.array = None
+            lib().crt_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SceneInput:
@@ -262,10 +291,12 @@ class Scene:
         _check(lib().crt_scene_get_traverse_mode(self._h, C.byref(m)), "crt_scene_get_traverse_mode")
         return m.value
 
-    def intersect(self, rays):
-        """n x intersectTest.  rays: float32 [n, 6] (origin, direction).  Returns HIT_DTYPE[n]."""
+    def intersect(self, rays, out=None):
+        """n x intersectTest.  rays: float32 [n, 6] (origin, direction).  Returns HIT_DTYPE[n]
+        (written into `out` when given, e.g. a HostBuffer array)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
-        hits = np.empty(len(rays), HIT_DTYPE)
+        hits = np.empty(len(rays), HIT_DTYPE) if out is None else out
+        assert hits.dtype == HIT_DTYPE and len(hits) == len(rays) and hits.flags.c_contiguous
         _check(lib().crt_intersect_batch(self._h, _ptr(rays), len(rays), _ptr(hits)), "crt_intersect_batch")
         return hits
 

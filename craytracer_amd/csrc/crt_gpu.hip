@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <vector>
 #include <new>
+#include <mutex>
 
 namespace {
 
@@ -51,6 +52,16 @@ struct crt_scene {
     unsigned* d_queue_head;   /* 256 B, word 0 used */
     unsigned* d_ovf_word; float* d_ovf_key; unsigned ovf_threads;
     hipEvent_t ev_start, ev_stop; bool ev_valid;
+    /* Every launch through this scene uses the one queue head and the one stack-overflow area, so
+     * launches are ordered: a launch waits (on the device) for the previous one's ev_stop even when
+     * it is enqueued on another stream.  The kernels are persistent and fill the GPU, so nothing
+     * is lost by that.  `mu` guards the launch sequence and the events against concurrent callers. */
+    std::mutex mu;
+    bool launched;
+    /* host-buffer entry points: two chunk-sized device buffers and two streams, created on first use */
+    void* d_chunk_in[2]; void* d_chunk_aux[2]; void* d_chunk_out[2]; void* d_chunk_out2[2];
+    size_t chunk_cap;         /* rays per chunk buffer */
+    hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
 
 namespace {
@@ -171,6 +182,11 @@ void free_scene(crt_scene* s)
     void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
                      s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        void* q[] = { s->d_chunk_in[k], s->d_chunk_aux[k], s->d_chunk_out[k], s->d_chunk_out2[k] };
+        for (void* p : q) if (p) (void)hipFree(p);
+        if (s->chunk_streams_valid) (void)hipStreamDestroy(s->chunk_stream[k]);
+    }
     if (s->ev_valid) { (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); }
     delete s;
 }
@@ -192,11 +208,14 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream)
     la.ovf_word = s->d_ovf_word;
     la.ovf_key = s->d_ovf_key;
     la.grid_threads = s->ovf_threads;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->launched) HIPCHK(hipStreamWaitEvent(stream, s->ev_stop, 0));     /* shared scratch: see crt_scene */
     HIPCHK(hipMemsetAsync(s->d_queue_head, 0, 256, stream));
     HIPCHK(hipEventRecord(s->ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev_stop, stream));
+    s->launched = true;
     return CRT_OK;
 }
 
@@ -269,8 +288,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
 
     crt_scene* s = new (std::nothrow) crt_scene();
     if (!s) return CRT_E_NOMEM;
-    memset(s, 0, sizeof *s);
-    s->device = device;
+    s->device = device;                         /* value-initialised above: every other field is zero */
     s->mode = CRT_TRAVERSE_AUTO;
     const int n = desc->num_obj, nng = desc->num_non_grid_obj;
 
@@ -422,21 +440,79 @@ int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_lig
     return s->count ? dispatch_shadow<false, true>(s, la, st) : dispatch_shadow<false, false>(s, la, st);
 }
 
+/* Host-buffer entry points.  The batch is cut into chunks that alternate between two streams,
+ * each doing  H2D(chunk) -> traversal kernel -> D2H(chunk)  in stream order, so the copies of one
+ * chunk overlap the kernel of the other (the kernels themselves are ordered by launch()).  With
+ * buffers from crt_host_alloc (pinned) the copies are DMA straight from / to the caller's memory;
+ * with ordinary malloc'd buffers HIP stages them and the calls are merely correct. */
+namespace {
+
+const size_t CRT_CHUNK_RAYS = (size_t)1 << 21;       /* 48 MB in, 40 MB out per chunk */
+
+int ensure_chunks(crt_scene* s, size_t need, bool shadow)
+{
+    if (!s->chunk_streams_valid) {
+        if (!hip_ok(hipStreamCreateWithFlags(&s->chunk_stream[0], hipStreamNonBlocking), "hipStreamCreate")) return CRT_E_HIP;
+        if (!hip_ok(hipStreamCreateWithFlags(&s->chunk_stream[1], hipStreamNonBlocking), "hipStreamCreate")) {
+            (void)hipStreamDestroy(s->chunk_stream[0]);
+            return CRT_E_HIP;
+        }
+        s->chunk_streams_valid = true;
+    }
+    if (need > s->chunk_cap) {
+        for (int k = 0; k < 2; k++) {
+            void** q[] = { &s->d_chunk_in[k], &s->d_chunk_aux[k], &s->d_chunk_out[k], &s->d_chunk_out2[k] };
+            for (void** p : q) { if (*p) (void)hipFree(*p); *p = 0; }
+        }
+        s->chunk_cap = 0;
+        for (int k = 0; k < 2; k++) {
+            if (!hip_ok(hipMalloc(&s->d_chunk_in[k], need * sizeof(crt_ray)), "hipMalloc") ||
+                !hip_ok(hipMalloc(&s->d_chunk_out[k], need * sizeof(crt_hit)), "hipMalloc") ||      /* hits, or shadow t (4 B) */
+                !hip_ok(hipMalloc(&s->d_chunk_aux[k], need * sizeof(float)), "hipMalloc") ||        /* light_dist */
+                !hip_ok(hipMalloc(&s->d_chunk_out2[k], need), "hipMalloc")) return CRT_E_NOMEM;     /* occluded */
+        }
+        s->chunk_cap = need;
+    }
+    (void)shadow;
+    return CRT_OK;
+}
+
+std::mutex g_chunk_mu;       /* one host-buffer call at a time per process: they share each scene's chunk buffers */
+
+} // namespace
+
+int crt_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return CRT_E_INVALID;
+    *out = 0;
+    if (bytes == 0) bytes = 1;
+    if (!hip_ok(hipHostMalloc(out, bytes, hipHostMallocDefault), "hipHostMalloc")) return CRT_E_NOMEM;
+    return CRT_OK;
+}
+void crt_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits)
 {
     if (!s || (n > 0 && (!rays || !hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
+    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
-    crt_ray* d_rays = 0; crt_hit* d_hits = 0;
-    int rc = CRT_OK;
-    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(crt_ray)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&d_hits, n * sizeof(crt_hit)), "hipMalloc")) rc = CRT_E_NOMEM;
-    if (rc == CRT_OK && !hip_ok(hipMemcpy(d_rays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice), "hipMemcpy H2D")) rc = CRT_E_HIP;
-    if (rc == CRT_OK) rc = crt_intersect_batch_dev(s, d_rays, n, d_hits, 0);
-    if (rc == CRT_OK && !hip_ok(hipMemcpy(hits, d_hits, n * sizeof(crt_hit), hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
-    if (d_rays) (void)hipFree(d_rays);
-    if (d_hits) (void)hipFree(d_hits);
+    std::lock_guard<std::mutex> lock(g_chunk_mu);
+    const size_t chunk = n < CRT_CHUNK_RAYS ? n : CRT_CHUNK_RAYS;
+    int rc = ensure_chunks(s, chunk, false);
+    int k = 0;
+    for (size_t off = 0; rc == CRT_OK && off < n; off += chunk, k ^= 1) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        hipStream_t st = s->chunk_stream[k];           /* stream order protects buffer k from its previous use */
+        if (!hip_ok(hipMemcpyAsync(s->d_chunk_in[k], rays + off, m * sizeof(crt_ray), hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D")) { rc = CRT_E_HIP; break; }
+        rc = crt_intersect_batch_dev(s, (const crt_ray*)s->d_chunk_in[k], m, (crt_hit*)s->d_chunk_out[k], st);
+        if (rc != CRT_OK) break;
+        if (!hip_ok(hipMemcpyAsync(hits + off, s->d_chunk_out[k], m * sizeof(crt_hit), hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H")) rc = CRT_E_HIP;
+    }
+    /* always drain both streams before the caller's buffers go out of our hands */
+    for (int j = 0; j < 2; j++)
+        if (s->chunk_streams_valid && !hip_ok(hipStreamSynchronize(s->chunk_stream[j]), "hipStreamSynchronize") && rc == CRT_OK) rc = CRT_E_HIP;
     return rc;
 }
 
@@ -445,24 +521,26 @@ int crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist,
 {
     if (!s || (n > 0 && (!rays || !light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
+    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
-    crt_ray* d_rays = 0; float* d_ld = 0; float* d_t = 0; uint8_t* d_occ = 0;
-    int rc = CRT_OK;
-    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(crt_ray)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&d_ld, n * sizeof(float)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&d_t, n * sizeof(float)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&d_occ, n), "hipMalloc")) rc = CRT_E_NOMEM;
-    if (rc == CRT_OK && (!hip_ok(hipMemcpy(d_rays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice), "hipMemcpy H2D") ||
-                         !hip_ok(hipMemcpy(d_ld, light_dist, n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy H2D"))) rc = CRT_E_HIP;
-    if (rc == CRT_OK) rc = crt_shadow_batch_dev(s, d_rays, d_ld, n, d_t, d_occ, 0);
-    if (rc == CRT_OK && t_out && !hip_ok(hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
-    if (rc == CRT_OK && occluded_out && !hip_ok(hipMemcpy(occluded_out, d_occ, n, hipMemcpyDeviceToHost), "hipMemcpy D2H")) rc = CRT_E_HIP;
-    if (rc == CRT_OK && !t_out && !occluded_out && !hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) rc = CRT_E_HIP;
-    if (d_rays) (void)hipFree(d_rays);
-    if (d_ld) (void)hipFree(d_ld);
-    if (d_t) (void)hipFree(d_t);
-    if (d_occ) (void)hipFree(d_occ);
+    std::lock_guard<std::mutex> lock(g_chunk_mu);
+    const size_t chunk = n < CRT_CHUNK_RAYS ? n : CRT_CHUNK_RAYS;
+    int rc = ensure_chunks(s, chunk, true);
+    int k = 0;
+    for (size_t off = 0; rc == CRT_OK && off < n; off += chunk, k ^= 1) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        hipStream_t st = s->chunk_stream[k];
+        if (!hip_ok(hipMemcpyAsync(s->d_chunk_in[k], rays + off, m * sizeof(crt_ray), hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D") ||
+            !hip_ok(hipMemcpyAsync(s->d_chunk_aux[k], light_dist + off, m * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D")) { rc = CRT_E_HIP; break; }
+        rc = crt_shadow_batch_dev(s, (const crt_ray*)s->d_chunk_in[k], (const float*)s->d_chunk_aux[k], m,
+                                  (float*)s->d_chunk_out[k], (uint8_t*)s->d_chunk_out2[k], st);
+        if (rc != CRT_OK) break;
+        if (t_out && !hip_ok(hipMemcpyAsync(t_out + off, s->d_chunk_out[k], m * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H")) { rc = CRT_E_HIP; break; }
+        if (occluded_out && !hip_ok(hipMemcpyAsync(occluded_out + off, s->d_chunk_out2[k], m, hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H")) { rc = CRT_E_HIP; break; }
+    }
+    for (int j = 0; j < 2; j++)
+        if (s->chunk_streams_valid && !hip_ok(hipStreamSynchronize(s->chunk_stream[j]), "hipStreamSynchronize") && rc == CRT_OK) rc = CRT_E_HIP;
     return rc;
 }
 
@@ -497,6 +575,8 @@ int crt_scene_last_kernel_ms(crt_scene* s, float* ms)
     if (!s || !ms) return CRT_E_INVALID;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->launched) return CRT_E_INVALID;
     HIPCHK(hipEventSynchronize(s->ev_stop));
     HIPCHK(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
     return CRT_OK;

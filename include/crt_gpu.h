@@ -187,7 +187,14 @@ void crt_scene_destroy(crt_scene* s);
 int  crt_scene_set_traverse_mode(crt_scene* s, int mode);
 int  crt_scene_get_traverse_mode(const crt_scene* s, int* resolved_mode);
 
-/* n x intersectTest (intersect.h:365-440).  Host buffers; copies in and out. */
+/* Page-locked host memory for ray / hit arrays.  No counterpart in the reference (it mallocs);
+ * buffers from here let the host-buffer calls below DMA straight from / to the caller's arrays
+ * and overlap the copies with the traversal kernels.  Ordinary malloc'd buffers work too, slower. */
+int  crt_host_alloc(size_t bytes, void** out);
+void crt_host_free(void* p);
+
+/* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose
+ * H2D copy, kernel and D2H copy are pipelined on two streams; returns when hits[] is complete. */
 int  crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits);
 /* n x shadowIntersectTest (intersect.h:443-545) + the caller's test
  * `in_shadow = t < light_dist - K_EPSILON` (trace.h:348).  t_out[i] is the value the
@@ -196,7 +203,10 @@ int  crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist
                       float* t_out, uint8_t* occluded_out);
 
 /* Same, all pointers DEVICE pointers on the scene's GPU; enqueued on `stream`
- * (a hipStream_t passed as void*, NULL = the null stream); returns without syncing. */
+ * (a hipStream_t passed as void*, NULL = the null stream); returns without syncing.
+ * Threading: any thread may call; launches through one crt_scene share its queue head and
+ * stack-overflow scratch, so the library orders them on the device (each waits for the previous
+ * one's completion event even across streams).  Use one crt_scene per GPU. */
 int  crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream);
 int  crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                           float* d_t_out, uint8_t* d_occluded_out, void* stream);

@@ -8,6 +8,6 @@ for n in "$@"; do
 import json,sys
 l=[x for x in open(sys.argv[2]) if x.startswith('{')][-1]
 j=json.loads(l)
-print(sys.argv[1], j['value'], 'Mrays/s kernel_ms', j['roofline']['kernel_ms'], 'nodes', j['roofline']['nodes_per_ray'], 'tris', j['roofline']['tris_per_ray'])
+print(sys.argv[1], j["value"], "chk", j["config"].get("hits_checksum"), 'Mrays/s kernel_ms', j['roofline']['kernel_ms'], 'nodes', j['roofline']['nodes_per_ray'], 'tris', j['roofline']['tris_per_ray'])
 PY
 done
