@@ -41,9 +41,11 @@ struct DevScene {
     int nng;                        /* num_non_grid_obj */
     int n_accel;                    /* num_obj - nng */
     int accel;
+    unsigned root_word;             /* child-word form of the QBVH root: axis2(root) << 28 | 0 */
 };
 
 #define CRT_LEAF_BIT 0x80000000u
+#define CRT_NODE_MASK 0x01FFFFFFu   /* inner child word: axis2 of the child << 28 | node index (< 2^25) */
 
 struct DRay { float ox, oy, oz, dx, dy, dz; };
 struct DHit { float t; int obj; int part; float beta; float gamma; };

@@ -134,6 +134,7 @@ int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
     *d4 = 0; *d2 = 0;
     if (d->accel == CRT_ACCEL_BVH4 && na > 0) {
         if (!d->nodes4 || d->num_nodes4 < 1) return CRT_E_INVALID;
+        if (d->num_nodes4 > (int)CRT_NODE_MASK) return CRT_E_TOOBIG;       /* 25-bit node index, 32-bit byte offsets */
         for (int i = 0; i < d->num_nodes4; i++) for (int c = 0; c < 4; c++) {
             const crt_bvh4_node& n = d->nodes4[i];
             if (n.type[c] == -1) { if (n.child[c] <= i || n.child[c] >= d->num_nodes4) return CRT_E_INVALID; }
@@ -321,8 +322,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 float4* q = &n4[(size_t)i * 8];
                 for (int k = 0; k < 6; k++) q[k] = make_float4(nd.bbox[4*k], nd.bbox[4*k+1], nd.bbox[4*k+2], nd.bbox[4*k+3]);
                 unsigned w[4];
-                for (int c = 0; c < 4; c++)
-                    w[c] = nd.type[c] == -1 ? (unsigned)nd.child[c]
+                for (int c = 0; c < 4; c++)       /* an inner word carries the child's own axis2: known at pop, no load */
+                    w[c] = nd.type[c] == -1 ? (((unsigned)(desc->nodes4[nd.child[c]].axis & 0x03) << 28) | (unsigned)nd.child[c])
                                             : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
                 float wf[4]; memcpy(wf, w, 16);
                 q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
@@ -384,6 +385,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.counters = s->d_counters;
     dv.grid = desc->grid;
     dv.num_obj = n; dv.nng = nng; dv.n_accel = n - nng; dv.accel = desc->accel;
+    dv.root_word = (desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0) ? ((unsigned)(desc->nodes4[0].axis & 0x03) << 28) : 0u;
     *out = s;
     return CRT_OK;
 }

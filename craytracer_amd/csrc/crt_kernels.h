@@ -131,6 +131,44 @@ CRT_DEV float box4(float mnx, float mny, float mnz, float mxx, float mxy, float 
     return hit ? t : CRT_TMAX;
 }
 
+/* The same test with the near / far planes already chosen (per-ray load offsets), returning the
+ * stack key directly: TMAX = not hit; -inf = hit with the origin inside / behind the box (the
+ * reference's `less_than && bbox_t < TMAX`, bvh4.h:358: always visited); else the box t. */
+CRT_DEV float box4_key_tail(float t0, float t1)
+{
+    const bool hit = (t0 < t1) && (t1 > CRT_K_EPSILON);
+    const float t = (t0 > CRT_K_EPSILON) ? t0 : t1;
+    const float b = hit ? t : CRT_TMAX;
+    return ((t0 < CRT_K_EPSILON) && (b < CRT_TMAX)) ? -__builtin_huge_valf() : b;
+}
+/* SSE semantics spelled out: max(a, b) = a > b ? a : b, min(a, b) = a < b ? a : b (second operand
+ * when unordered) -- needed when a product can be NaN (zero direction component with the origin on
+ * a slab plane, bvh4.h:43-75). */
+CRT_DEV float box4_key_sse(float nx, float ny, float nz, float fx, float fy, float fz,
+                           const DRay& r, float ia, float ib, float ic)
+{
+    const float tx_min = (nx - r.ox) * ia, tx_max = (fx - r.ox) * ia;
+    const float ty_min = (ny - r.oy) * ib, ty_max = (fy - r.oy) * ib;
+    const float tz_min = (nz - r.oz) * ic, tz_max = (fz - r.oz) * ic;
+    const float m0 = tx_min > ty_min ? tx_min : ty_min;
+    const float t0 = m0 > tz_min ? m0 : tz_min;
+    const float m1 = tx_max < ty_max ? tx_max : ty_max;
+    const float t1 = m1 < tz_max ? m1 : tz_max;
+    return box4_key_tail(t0, t1);
+}
+/* No operand can be NaN (see `clean`): the chains select the same values as v_max3 / v_min3
+ * (a zero may come out with the other sign; it is only compared afterwards, never returned). */
+CRT_DEV float box4_key_fast(float nx, float ny, float nz, float fx, float fy, float fz,
+                            const DRay& r, float ia, float ib, float ic)
+{
+    const float tx_min = (nx - r.ox) * ia, tx_max = (fx - r.ox) * ia;
+    const float ty_min = (ny - r.oy) * ib, ty_max = (fy - r.oy) * ib;
+    const float tz_min = (nz - r.oz) * ic, tz_max = (fz - r.oz) * ic;
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(tx_min, ty_min), tz_min);
+    const float t1 = __builtin_fminf(__builtin_fminf(tx_max, ty_max), tz_max);
+    return box4_key_tail(t0, t1);
+}
+
 /* Linear pass over objects[first, last) -- the non-grid loops of intersectTest
  * (intersect.h:387-395,:403-411) and the NONE branch (:416-432): strict `<`. */
 template <bool TRI_ONLY, bool COUNT>
@@ -213,7 +251,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
-    bool sx = true, sy = true, sz = true, px = true, walking = false;
+    bool px = true, walking = false;
+    /* byte offsets, inside a node, of the plane rows the ray enters / leaves through: the
+     * `d >= 0 ? min : max` selects of bvh4.h:43-75 done once per ray instead of once per box */
+    unsigned onx = 0, ofx = 48, ony = 16, ofy = 64, onz = 32, ofz = 80;
+    unsigned pbits = 7;           /* bit a = (d[a] > 0) */
+    bool clean = true;            /* no product of the slab test can be NaN for this ray */
+    bool wave_clean = true;       /* wave-uniform: every ray loaded so far into this wave was clean */
     float best_t = CRT_TMAX;
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
@@ -225,40 +269,58 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                 ri = idx;
                 ray = load_ray(la.rays, ri);
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
-                sx = ray.dx >= 0.0f; sy = ray.dy >= 0.0f; sz = ray.dz >= 0.0f;        /* bvh4.h:43,:54,:65 */
+                const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
+                onx = sx ? 0u : 48u;  ofx = 48u - onx;
+                ony = sy ? 16u : 64u; ofy = 80u - ony;
+                onz = sz ? 32u : 80u; ofz = 112u - onz;
                 px = ray.dx > 0.0f;                                                    /* bvh4.h:312 (axis0 = axis1 = 0) */
+                pbits = (px ? 1u : 0u) | (ray.dy > 0.0f ? 2u : 0u) | (ray.dz > 0.0f ? 4u : 0u);
+                /* finite non-zero 1/d and a finite origin: every (plane - o) * (1/d) is then a number
+                 * (possibly +-inf), never NaN, and max3 / min3 equal the SSE max / min chains */
+                clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
+                        fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
+                        ia != 0.0f && ib != 0.0f && ic != 0.0f;
                 best_t = CRT_TMAX;
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
                 st.sp = 0;
-                cur = 0;                                                               /* root */
+                cur = sc.root_word;
                 walking = sc.n_accel > 0;
                 alive = true;
             }
+            if (__ballot(alive && !clean) != 0ull) wave_clean = false;
         }
         if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
         if (alive) {
             if (walking) {
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
-                    const float4* nd = sc.nodes4 + (size_t)cur * 8;
-                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
+                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
+                    const int ax2 = (int)((cur >> 28) & 3u);
+                    const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
+                    const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
+                    const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
+                    const float4 ny = *reinterpret_cast<const float4*>(nbase + (nb + ony));
+                    const float4 fy = *reinterpret_cast<const float4*>(nbase + (nb + ofy));
+                    const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
+                    const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
+                    const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
                     if (COUNT) c_nodes++;
-                    bool l0, l1, l2, l3;
-                    const float b0 = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &l0);
-                    const float b1 = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &l1);
-                    const float b2 = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &l2);
-                    const float b3 = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &l3);
-                    /* key: -inf for "origin inside/behind the box" children (always visited when hit) */
-                    const float ninf = -__builtin_huge_valf();
-                    const float k0 = (l0 && b0 < CRT_TMAX) ? ninf : b0;
-                    const float k1 = (l1 && b1 < CRT_TMAX) ? ninf : b1;
-                    const float k2 = (l2 && b2 < CRT_TMAX) ? ninf : b2;
-                    const float k3 = (l3 && b3 < CRT_TMAX) ? ninf : b3;
+                    float k0, k1, k2, k3;
+                    if (wave_clean) {
+                        k0 = box4_key_fast(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
+                        k1 = box4_key_fast(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
+                        k2 = box4_key_fast(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
+                        k3 = box4_key_fast(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
+                    } else {
+                        k0 = box4_key_sse(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
+                        k1 = box4_key_sse(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
+                        k2 = box4_key_sse(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
+                        k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
+                    }
                     const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
                     const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
-                    const int ax2 = __float_as_int(q7.x);
-                    const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
-                    const bool p2 = dax > 0.0f;                                       /* bvh4.h:323,:334 */
+                    const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
                     /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
                     const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
                     const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
@@ -357,7 +419,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
             if (walking) {
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
-                    const float4* nd = sc.nodes4 + (size_t)cur * 8;
+                    const float4* nd = sc.nodes4 + (size_t)(cur & CRT_NODE_MASK) * 8;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
                     if (COUNT) c_nodes++;
                     bool l0, l1, l2, l3;
@@ -716,7 +778,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest_exact(DevScene sc, L
                             if (depth + 1 < CRT_EXACT4_DEPTH) {
                                 fr[depth] = f;
                                 depth++;
-                                fr[depth].node = w; fr[depth].k = 0; fr[depth].local_t = CRT_TMAX; fr[depth].hit = ret_h;
+                                fr[depth].node = w & CRT_NODE_MASK; fr[depth].k = 0; fr[depth].local_t = CRT_TMAX; fr[depth].hit = ret_h;
                                 descended = true;
                                 break;
                             }
