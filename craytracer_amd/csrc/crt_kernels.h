@@ -169,6 +169,23 @@ CRT_DEV float box4_key_fast(float nx, float ny, float nz, float fx, float fy, fl
     return box4_key_tail(t0, t1);
 }
 
+/* two boxes at a time so that the subtract / multiply pairs become v_pk_add_f32 / v_pk_mul_f32
+ * (each lane of a packed op rounds like the scalar op; contraction is off) */
+typedef float v2f __attribute__((ext_vector_type(2)));
+CRT_DEV void box4_keys_fast2(v2f nx, v2f ny, v2f nz, v2f fx, v2f fy, v2f fz,
+                             const DRay& r, float ia, float ib, float ic, float* ka, float* kb)
+{
+    const v2f ox = {r.ox, r.ox}, oy = {r.oy, r.oy}, oz = {r.oz, r.oz};
+    const v2f ia2 = {ia, ia}, ib2 = {ib, ib}, ic2 = {ic, ic};
+    const v2f tx_min = (nx - ox) * ia2, tx_max = (fx - ox) * ia2;
+    const v2f ty_min = (ny - oy) * ib2, ty_max = (fy - oy) * ib2;
+    const v2f tz_min = (nz - oz) * ic2, tz_max = (fz - oz) * ic2;
+    *ka = box4_key_tail(__builtin_fmaxf(__builtin_fmaxf(tx_min.x, ty_min.x), tz_min.x),
+                        __builtin_fminf(__builtin_fminf(tx_max.x, ty_max.x), tz_max.x));
+    *kb = box4_key_tail(__builtin_fmaxf(__builtin_fmaxf(tx_min.y, ty_min.y), tz_min.y),
+                        __builtin_fminf(__builtin_fminf(tx_max.y, ty_max.y), tz_max.y));
+}
+
 /* Linear pass over objects[first, last) -- the non-grid loops of intersectTest
  * (intersect.h:387-395,:403-411) and the NONE branch (:416-432): strict `<`. */
 template <bool TRI_ONLY, bool COUNT>
@@ -308,10 +325,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     if (COUNT) c_nodes++;
                     float k0, k1, k2, k3;
                     if (wave_clean) {
-                        k0 = box4_key_fast(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
-                        k1 = box4_key_fast(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
-                        k2 = box4_key_fast(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
-                        k3 = box4_key_fast(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
+                        box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
+                                        ray, ia, ib, ic, &k0, &k1);
+                        box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
+                                        ray, ia, ib, ic, &k2, &k3);
                     } else {
                         k0 = box4_key_sse(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
                         k1 = box4_key_sse(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
