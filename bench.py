@@ -97,6 +97,37 @@ def gen_incoherent_rays(sc, si, n_rays, seed, device):
     return allr[:n_rays].contiguous()
 
 
+def gen_shadow_rays(sc, si, d_rays, seed, device):
+    """R-shadow: from the hit points of the incoherent rays toward uniformly sampled
+    points on a rectangle light under the ceiling; light_dist = distance (trace.h:253-260,:337).
+    Origin = hit point, no offset (the reference offsets nothing)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = d_rays.shape[0]
+    tri = torch.from_numpy(si.tri_verts).to(device).view(-1, 3)
+    lo, hi = tri.min(0).values, tri.max(0).values
+    hits = torch.empty((n, 5), dtype=torch.int32, device=device)
+    sc.enable_counters(True)
+    sc.intersect_dev(d_rays.data_ptr(), n, hits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sc.enable_counters(False)
+    sc.reset_counters()
+    t = hits[:, 0].view(torch.float32)
+    ok = hits[:, 1] >= 0
+    p = torch.where(ok[:, None], d_rays[:, :3] + d_rays[:, 3:] * t[:, None], d_rays[:, :3])
+    c = (lo + hi) * 0.5
+    ext = (hi - lo) * 0.1
+    q = torch.empty((n, 3), device=device)
+    q[:, 0] = c[0] + (torch.rand(n, generator=g, device=device) * 2 - 1) * ext[0]
+    q[:, 2] = c[2] + (torch.rand(n, generator=g, device=device) * 2 - 1) * ext[2]
+    q[:, 1] = hi[1] - (hi[1] - lo[1]) * 0.002
+    v = q - p
+    ld = v.norm(dim=1).clamp_min(1e-6)
+    rays = torch.cat([p, v / ld[:, None]], 1).float().contiguous()
+    return rays, ld.float().contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +137,8 @@ def main():
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
+                    help="closest = the headline metric; shadow = the secondary any-hit metric")
     args = ap.parse_args()
 
     import torch
@@ -137,9 +170,17 @@ def main():
     d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
     d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
+    shadow = args.mode == "shadow"
+    if shadow:
+        d_rays, d_ld = gen_shadow_rays(sc, si, d_rays, 0xBEEF + rank, device)
+        d_t = torch.empty(n, dtype=torch.float32, device=device)
+        d_occ = torch.empty(n, dtype=torch.uint8, device=device)
 
     def step():
-        sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream)
+        if shadow:
+            sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), n, d_t.data_ptr(), d_occ.data_ptr(), stream)
+        else:
+            sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,6 +198,8 @@ def main():
     tris_per_ray = cnt["prims_tested"] / n
     # 24 (ray in) + 20 (hit out) + 128 per QBVH node + 36 + 4 per triangle tested
     bytes_per_ray = 24 + 20 + 128 * nodes_per_ray + 40 * tris_per_ray
+    if shadow:        # ray + light_dist in, t + occluded out
+        bytes_per_ray = 28 + 5 + 128 * nodes_per_ray + 40 * tris_per_ray
 
     for _ in range(args.warmup):
         step()
@@ -169,8 +212,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = shard.max_over_ranks(elapsed, device)
-    hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
-    checksum = int(d_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF      # same scene + rays => same number
+    if shadow:
+        hit_frac = float(d_occ.float().mean().item())
+        checksum = int(d_t.view(torch.int32).to(torch.int64).sum().item() + d_occ.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF
+    else:
+        hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
+        checksum = int(d_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF  # same scene + rays => same number
 
     total_rays = float(n) * world * args.steps
     value = total_rays / elapsed / 1e6
@@ -178,25 +225,26 @@ def main():
     achieved_gbs = bytes_per_ray * n / (avg_kernel_ms * 1e-3) / 1e9
 
     out = {
-        "metric": "Mrays/s closest-hit (incoherent), QBVH",
+        "metric": "Mrays/s any-hit (shadow rays toward an area light), QBVH" if shadow else "Mrays/s closest-hit (incoherent), QBVH",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), QBVH, %d incoherent "
-                               "bounce-1..3 rays per GPU per step" % (args.workload, n_tris, n),
-                   "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "pruned",
+        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), QBVH, %d %s per GPU per step"
+                               % (args.workload, n_tris, n, "shadow rays from the incoherent hit points toward a ceiling light"
+                                  if shadow else "incoherent bounce-1..3 rays"),
+                   "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "reference order, first hit ends the walk" if shadow else "pruned",
                    "parallelism": "scene replica per GPU, rays sharded, no collective", "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
                    "scene_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4),
+                     "kernel": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4),
                      "bytes_per_ray": round(bytes_per_ray, 2), "nodes_per_ray": round(nodes_per_ray, 3),
                      "tris_per_ray": round(tris_per_ray, 3)},
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file)).get(args.workload)
+            tr = json.load(open(traffic_file)).get(args.workload + ("/shadow" if shadow else ""))
             if tr and tr.get("rays") == n:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
         except Exception:
@@ -209,24 +257,32 @@ def main():
         o = ol.OracleScene(si, built=built)
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         host_rays = d_rays.cpu().numpy()
-        probe = host_rays[: 1 << 16]
+        host_ld = d_ld.cpu().numpy() if shadow else None
+
+        def cpu(lo_, hi_, threads):
+            if shadow:
+                return o.shadow(host_rays[lo_:hi_], host_ld[lo_:hi_], nthreads=threads)
+            return o.intersect(host_rays[lo_:hi_], mode=api.TRAVERSE_EXACT, nthreads=threads)
+
         t1 = time.perf_counter()
-        o.intersect(probe, mode=api.TRAVERSE_EXACT, nthreads=cores)
-        rate = len(probe) / max(time.perf_counter() - t1, 1e-6)
-        m = int(min(len(host_rays), max(len(probe), rate * args.cpu_seconds)))
-        sample = host_rays[:m]
+        cpu(0, 1 << 16, cores)
+        rate = (1 << 16) / max(time.perf_counter() - t1, 1e-6)
+        m = int(min(len(host_rays), max(1 << 16, rate * args.cpu_seconds)))
         t1 = time.perf_counter()
-        ref_hits = o.intersect(sample, mode=api.TRAVERSE_EXACT, nthreads=cores)
+        ref = cpu(0, m, cores)
         cpu_s = time.perf_counter() - t1
         m1 = max(m // (2 * cores), 1)
         t1 = time.perf_counter()
-        o.intersect(sample[:m1], mode=api.TRAVERSE_EXACT, nthreads=1)
+        cpu(0, m1, 1)
         cpu1_s = time.perf_counter() - t1
-        gpu_hits = d_hits[:m].cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
-        same = bool(ol.same_bits(gpu_hits, ref_hits))
+        if shadow:
+            same = bool(ol.same_bits(d_t[:m].cpu().numpy(), ref[0])) and \
+                bool(np.array_equal(d_occ[:m].cpu().numpy().astype(bool), ref[1]))
+        else:
+            gpu_hits = d_hits[:m].cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
+            same = bool(ol.same_bits(gpu_hits, ref))
         out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                               "sample": "first %d rays of the GPU batch, oracle in the reference's control flow "
-                                         "(min_t local to each node), %.1f s" % (m, cpu_s),
+                               "sample": "first %d rays of the GPU batch, oracle in the reference's control flow, %.1f s" % (m, cpu_s),
                                "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4),
                                "gpu_bit_identical_on_sample": same}
     if rank == 0:

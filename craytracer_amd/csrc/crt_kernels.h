@@ -78,6 +78,28 @@ struct LaneStack {
     }
 };
 
+/* words only (any-hit walks need no key): 4-byte entries, half the LDS, more resident waves */
+__device__ __noinline__ void ovf_push32(unsigned* ovf_word, size_t o, unsigned w) { ovf_word[o] = w; }
+__device__ __noinline__ unsigned ovf_pop32(const unsigned* ovf_word, size_t o) { return ovf_word[o]; }
+struct LaneStack32 {
+    unsigned (*lds)[CRT_BLOCK];
+    unsigned* ovf_word;
+    unsigned ovf_stride;
+    int sp;
+    CRT_DEV void push(unsigned w)
+    {
+        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) lds[sp][threadIdx.x] = w;
+        else if (sp < CRT_STACK_MAX) ovf_push32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride, w);
+        sp++;
+    }
+    CRT_DEV unsigned pop()
+    {
+        sp--;
+        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) return lds[sp][threadIdx.x];
+        return ovf_pop32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride);
+    }
+};
+
 CRT_DEV DRay load_ray(const crt_ray* rays, unsigned i)
 {
     const float2* p = reinterpret_cast<const float2*>(rays + i);    /* 24-B records, 8-B aligned */
@@ -397,12 +419,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
 template <bool TRI_ONLY, bool COUNT>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchArgs la)
 {
-    __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ unsigned s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
-    LaneStack st;
+    LaneStack32 st;
     st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
-    st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
     st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
@@ -411,7 +432,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f, ld = 0.0f, result = CRT_TMAX;
-    bool sx = true, sy = true, sz = true, px = true, walking = false;
+    bool px = true, walking = false;
+    unsigned onx = 0, ofx = 48, ony = 16, ofy = 64, onz = 32, ofz = 80, pbits = 7;   /* as in k_bvh4_closest */
+    bool clean = true, wave_clean = true;
+    const float ninf = -__builtin_huge_valf();
 
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
@@ -422,57 +446,79 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                 ray = load_ray(la.rays, ri);
                 ld = la.light_dist[ri];
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;
-                sx = ray.dx >= 0.0f; sy = ray.dy >= 0.0f; sz = ray.dz >= 0.0f;
+                const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
+                onx = sx ? 0u : 48u;  ofx = 48u - onx;
+                ony = sy ? 16u : 64u; ofy = 80u - ony;
+                onz = sz ? 32u : 80u; ofz = 112u - onz;
                 px = ray.dx > 0.0f;
+                pbits = (px ? 1u : 0u) | (ray.dy > 0.0f ? 2u : 0u) | (ray.dz > 0.0f ? 4u : 0u);
+                clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
+                        fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
+                        ia != 0.0f && ib != 0.0f && ic != 0.0f;
                 result = CRT_TMAX;
                 st.sp = 0;
-                cur = 0;
+                cur = sc.root_word;
                 walking = sc.n_accel > 0;
                 alive = true;
             }
+            if (__ballot(alive && !clean) != 0ull) wave_clean = false;
         }
         if (__ballot(alive) == 0ull) break;
         if (alive) {
             if (walking) {
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
-                    const float4* nd = sc.nodes4 + (size_t)(cur & CRT_NODE_MASK) * 8;
-                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
+                    const int ax2 = (int)((cur >> 28) & 3u);
+                    const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
+                    const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
+                    const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
+                    const float4 ny = *reinterpret_cast<const float4*>(nbase + (nb + ony));
+                    const float4 fy = *reinterpret_cast<const float4*>(nbase + (nb + ofy));
+                    const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
+                    const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
+                    const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
                     if (COUNT) c_nodes++;
-                    bool l0, l1, l2, l3;
-                    const float b0 = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &l0);
-                    const float b1 = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &l1);
-                    const float b2 = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &l2);
-                    const float b3 = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &l3);
-                    const bool v0 = b0 < ld || (l0 && b0 < CRT_TMAX);                 /* bvh4.h:450 */
-                    const bool v1 = b1 < ld || (l1 && b1 < CRT_TMAX);
-                    const bool v2 = b2 < ld || (l2 && b2 < CRT_TMAX);
-                    const bool v3 = b3 < ld || (l3 && b3 < CRT_TMAX);
+                    float k0, k1, k2, k3;
+                    if (wave_clean) {
+                        box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
+                                        ray, ia, ib, ic, &k0, &k1);
+                        box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
+                                        ray, ia, ib, ic, &k2, &k3);
+                    } else {
+                        k0 = box4_key_sse(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
+                        k1 = box4_key_sse(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
+                        k2 = box4_key_sse(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
+                        k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
+                    }
+                    /* bvh4.h:450: bbox_t < light_dist || (less_than && bbox_t < TMAX); key = -inf encodes the latter */
+                    const bool v0 = k0 < ld || k0 == ninf, v1 = k1 < ld || k1 == ninf;
+                    const bool v2 = k2 < ld || k2 == ninf, v3 = k3 < ld || k3 == ninf;
                     const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
                     const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
-                    const int ax2 = __float_as_int(q7.x);
-                    const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
-                    const bool p2 = dax > 0.0f;
+                    const bool p2 = ((pbits >> ax2) & 1u) != 0u;
                     const bool vC = p2 ? v2 : v3, vD = p2 ? v3 : v2;
                     const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
                     const bool s0v = px ? v0 : vC, s1v = px ? v1 : vD, s2v = px ? vC : v1, s3v = px ? vD : v0;
                     const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
-                    if (s3v) st.push(s3w, 0.0f);
-                    if (s2v) st.push(s2w, 0.0f);
-                    if (s1v) st.push(s1w, 0.0f);
+                    if (s3v) st.push(s3w);
+                    if (s2v) st.push(s2w);
+                    if (s1v) st.push(s1w);
                     if (s0v) { cur = s0w; need_pop = false; }
                 } else {
+                    /* one object of the leaf per step, in array order (bvh4.h:464-472) */
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
-                    for (int j = 0; j < count; j++) {                                 /* bvh4.h:464-472 */
+                    if (count > 0) {
                         DHit h;
-                        const float t = dev_object<TRI_ONLY>(sc, first + j, ray, true, &h);
+                        const float t = dev_object<TRI_ONLY>(sc, first, ray, true, &h);
                         if (COUNT) c_prims++;
-                        if (t < ld) { result = t; walking = false; need_pop = false; break; }
+                        if (t < ld) { result = t; walking = false; need_pop = false; }
                     }
+                    if (walking && count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
                 }
                 if (need_pop) {
-                    if (st.sp > 0) { float key; st.pop(&cur, &key); }
+                    if (st.sp > 0) cur = st.pop();
                     else walking = false;
                 }
             }

@@ -159,3 +159,27 @@ def test_brute_force_sample(case):
     differ = brute["obj"] != got["obj"]          # only exact-t ties (shared edges) may name another triangle
     assert differ.mean() < 1e-3
     assert (brute["t"][differ] == got["t"][differ]).all()
+
+
+def test_any_hit_oracle_on_a_sample(case):
+    """Shadow rays from the hit points toward a ceiling light (bench.gen_shadow_rays): the first-found
+    t of the reference's walk order (class T5) and the caller's boolean, bit-identical to the oracle,
+    and the kernel's node / primitive counters equal to the oracle's."""
+    import torch
+    import bench
+    m = 1 << 18
+    sc = case["sc"]
+    d_rays, d_ld = bench.gen_shadow_rays(sc, case["si"], case["d_rays"][:m].contiguous(), 99, torch.device("cuda", 0))
+    d_t = torch.empty(m, dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(m, dtype=torch.uint8, device="cuda")
+    sc.enable_counters(True)
+    sc.reset_counters()
+    sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), m, d_t.data_ptr(), d_occ.data_ptr(), None)
+    cnt = sc.counters()
+    sc.enable_counters(False)
+    o = ol.OracleScene(case["si"], built=case["built"])
+    t, occ, oc = o.shadow(d_rays.cpu().numpy(), d_ld.cpu().numpy(), nthreads=min(os.cpu_count() or 1, 16), counters=True)
+    assert ol.same_bits(d_t.cpu().numpy(), t)
+    assert np.array_equal(d_occ.cpu().numpy().astype(bool), occ)
+    assert 0.02 < occ.mean() < 0.98
+    assert cnt["nodes_visited"] == oc["nodes_visited"] and cnt["prims_tested"] == oc["prims_tested"]
