@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--binning", default="on", choices=["on", "off"],
+                    help="the library's ray binning step (inside the timed region); off = arrival order")
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
     args = ap.parse_args()
@@ -162,6 +164,7 @@ def main():
     si = scenes.courtyard(n_copies, n_lat, n_lon, seed=5)
     built = api.BuiltScene(si, api.ACCEL_BVH4)
     sc = api.Scene(built, local_rank)
+    sc.set_ray_binning(args.binning == "on")
     build_s = time.time() - t0
     n_tris = si.num_obj
 
@@ -196,19 +199,22 @@ def main():
     sc.enable_counters(False)
     nodes_per_ray = cnt["nodes_visited"] / n
     tris_per_ray = cnt["prims_tested"] / n
-    # 24 (ray in) + 20 (hit out) + 128 per QBVH node + 36 + 4 per triangle tested
-    bytes_per_ray = 24 + 20 + 128 * nodes_per_ray + 40 * tris_per_ray
+    # 24 (ray in) + 20 (hit out) + one QBVH node per visit + 36 + 4 per triangle tested.
+    # A node visit reads 112 of the node's 128 bytes (6 plane rows + the child words; the axis byte
+    # travels in the parent's child word), so 112 is what is charged, not SURVEY's planning value 128.
+    bytes_per_ray = 24 + 20 + 112 * nodes_per_ray + 40 * tris_per_ray
     if shadow:        # ray + light_dist in, t + occluded out
-        bytes_per_ray = 28 + 5 + 128 * nodes_per_ray + 40 * tris_per_ray
+        bytes_per_ray = 28 + 5 + 112 * nodes_per_ray + 40 * tris_per_ray
 
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
+    kernel_ms, bin_ms = [], []
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
         kernel_ms.append(sc.last_kernel_ms())      # HIP events on the launch stream (syncs the step)
+        bin_ms.append(sc.last_binning_ms())
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = shard.max_over_ranks(elapsed, device)
@@ -233,11 +239,11 @@ def main():
                                % (args.workload, n_tris, n, "shadow rays from the incoherent hit points toward a ceiling light"
                                   if shadow else "incoherent bounce-1..3 rays"),
                    "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "reference order, first hit ends the walk" if shadow else "pruned",
-                   "parallelism": "scene replica per GPU, rays sharded, no collective", "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
+                   "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
                    "scene_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4),
+                     "kernel": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4), "binning_ms": round(float(np.mean(bin_ms)), 4),
                      "bytes_per_ray": round(bytes_per_ray, 2), "nodes_per_ray": round(nodes_per_ray, 3),
                      "tris_per_ray": round(tris_per_ray, 3)},
     }

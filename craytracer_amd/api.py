@@ -82,11 +82,11 @@ class CrtCounters(C.Structure):
 EXPORTS = [
     "crt_build_scene", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
-    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode",
+    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
     "crt_host_alloc", "crt_host_free",
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
-    "crt_scene_last_kernel_ms", "crt_strerror", "crt_last_hip_error",
+    "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
     L.crt_scene_destroy.restype = None
     L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
     L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.crt_scene_set_ray_binning.argtypes = [vp, C.c_int]
     L.crt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.crt_host_free.argtypes = [vp]
     L.crt_host_free.restype = None
@@ -132,6 +133,7 @@ def lib():
     L.crt_scene_get_counters.argtypes = [vp, C.POINTER(CrtCounters)]
     L.crt_scene_reset_counters.argtypes = [vp]
     L.crt_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crt_scene_last_binning_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_strerror.restype = C.c_char_p
     L.crt_last_hip_error.argtypes = []
@@ -286,6 +288,9 @@ class Scene:
     def set_traverse_mode(self, mode):
         _check(lib().crt_scene_set_traverse_mode(self._h, int(mode)), "crt_scene_set_traverse_mode")
 
+    def set_ray_binning(self, on=True):
+        _check(lib().crt_scene_set_ray_binning(self._h, 1 if on else 0), "crt_scene_set_ray_binning")
+
     def traverse_mode(self):
         m = C.c_int()
         _check(lib().crt_scene_get_traverse_mode(self._h, C.byref(m)), "crt_scene_get_traverse_mode")
@@ -328,6 +333,11 @@ class Scene:
 
     def reset_counters(self):
         _check(lib().crt_scene_reset_counters(self._h), "crt_scene_reset_counters")
+
+    def last_binning_ms(self):
+        m = C.c_float()
+        _check(lib().crt_scene_last_binning_ms(self._h, C.byref(m)), "crt_scene_last_binning_ms")
+        return m.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -7,6 +7,7 @@
  * a batch of hit records back.
  */
 #include "crt_kernels.h"
+#include "crt_binning.h"
 
 #include <string.h>
 #include <stdio.h>
@@ -51,7 +52,7 @@ struct crt_scene {
     unsigned long long* d_counters;
     unsigned* d_queue_head;   /* 256 B, word 0 used */
     unsigned* d_ovf_word; float* d_ovf_key; unsigned ovf_threads;
-    hipEvent_t ev_start, ev_stop; bool ev_valid;
+    hipEvent_t ev_bin, ev_start, ev_stop; bool ev_valid; bool last_binned;
     /* Every launch through this scene uses the one queue head and the one stack-overflow area, so
      * launches are ordered: a launch waits (on the device) for the previous one's ev_stop even when
      * it is enqueued on another stream.  The kernels are persistent and fill the GPU, so nothing
@@ -61,6 +62,9 @@ struct crt_scene {
     /* host-buffer entry points: two chunk-sized device buffers and two streams, created on first use */
     void* d_chunk_in[2]; void* d_chunk_aux[2]; void* d_chunk_out[2]; void* d_chunk_out2[2];
     size_t chunk_cap;         /* rays per chunk buffer */
+    /* ray binning (crt_binning.h): triangle-only QBVH scenes, batches of at least CRT_BIN_MIN_RAYS */
+    bool binning; BinGrid bin_grid; bool bin_grid_valid;
+    unsigned* d_bin_hist; unsigned* d_bin_cursor; unsigned* d_perm; size_t perm_cap;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
 
@@ -181,21 +185,24 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
-                     s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key };
+                     s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key,
+                     s->d_bin_hist, s->d_bin_cursor, s->d_perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
         void* q[] = { s->d_chunk_in[k], s->d_chunk_aux[k], s->d_chunk_out[k], s->d_chunk_out2[k] };
         for (void* p : q) if (p) (void)hipFree(p);
         if (s->chunk_streams_valid) (void)hipStreamDestroy(s->chunk_stream[k]);
     }
-    if (s->ev_valid) { (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); }
+    if (s->ev_valid) { (void)hipEventDestroy(s->ev_bin); (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); }
     delete s;
 }
 
 /* ---- launch ------------------------------------------------------------------------- */
 
+const unsigned CRT_BIN_MIN_RAYS = 1u << 18;
+
 template <class K>
-int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream)
+int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false)
 {
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CRT_BLOCK, 0));
@@ -212,6 +219,24 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream)
     std::lock_guard<std::mutex> lock(s->mu);
     if (s->launched) HIPCHK(hipStreamWaitEvent(stream, s->ev_stop, 0));     /* shared scratch: see crt_scene */
     HIPCHK(hipMemsetAsync(s->d_queue_head, 0, 256, stream));
+    la.perm = 0;
+    s->last_binned = false;
+    if (use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS) {
+        if (la.n > s->perm_cap) {                     /* grows only; the previous launch has been waited for above */
+            HIPCHK(hipStreamSynchronize(stream));
+            if (s->d_perm) { (void)hipFree(s->d_perm); s->d_perm = 0; s->perm_cap = 0; }
+            if (!hip_ok(hipMalloc((void**)&s->d_perm, (size_t)la.n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
+            s->perm_cap = la.n;
+        }
+        HIPCHK(hipEventRecord(s->ev_bin, stream));
+        s->last_binned = true;
+        const unsigned bb = (la.n + CRT_BIN_CHUNK - 1) / CRT_BIN_CHUNK;
+        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, s->d_bin_hist);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, s->d_bin_hist, s->d_bin_cursor);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, s->d_bin_cursor, s->d_perm);
+        HIPCHK(hipGetLastError());
+        la.perm = s->d_perm;
+    }
     HIPCHK(hipEventRecord(s->ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
     HIPCHK(hipGetLastError());
@@ -226,7 +251,7 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest_exact<TRI_ONLY, COUNT>, la, st)
-                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT>, la, st);
+                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT>, la, st, true);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, false>, la, st)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false>, la, st);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st);
@@ -238,7 +263,7 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st);
+    case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, true>, la, st)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true>, la, st);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
@@ -311,6 +336,28 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         }
         s->tri_only = all_tri;
         s->accel_tri_only = accel_tri;
+        if (desc->accel == CRT_ACCEL_BVH4 && n - nng > 0) {          /* box of the triangles under the accelerator */
+            float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
+            bool any = false;
+            for (int i = nng; i < n; i++) {
+                const int t = desc->obj_type[i];
+                if (!(t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE)) continue;
+                const float* v = desc->tri_verts + (size_t)desc->obj_ref[i] * 9;
+                for (int k = 0; k < 9; k++) {
+                    const float x = v[k];
+                    if (x == x && x > -1.0e30f && x < 1.0e30f) { if (x < lo[k % 3]) lo[k % 3] = x; if (x > hi[k % 3]) hi[k % 3] = x; any = true; }
+                }
+            }
+            if (any) {
+                for (int a = 0; a < 3; a++) {
+                    const float ext = hi[a] - lo[a];
+                    s->bin_grid.lo[a] = lo[a];
+                    s->bin_grid.scale[a] = ext > 0.0f ? (float)(1 << CRT_BIN_BITS) / ext : 0.0f;
+                }
+                s->bin_grid_valid = true;
+            }
+        }
+        s->binning = true;
         if (desc->accel == CRT_ACCEL_BVH4 && !accel_tri && d4 > CRT_EXACT4_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
         if (desc->accel == CRT_ACCEL_BVH && !accel_tri && d2 > CRT_EXACT2_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
 
@@ -369,10 +416,14 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     if (!hip_ok(hipMalloc((void**)&s->d_ovf_word, ovf_bytes), "hipMalloc") ||
         !hip_ok(hipMalloc((void**)&s->d_ovf_key, ovf_bytes), "hipMalloc") ||
         !hip_ok(hipMalloc((void**)&s->d_queue_head, 256), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+        !hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->d_bin_hist, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->d_bin_cursor, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    if (!hip_ok(hipMemset(s->d_bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset") ||
         !hip_ok(hipEventCreate(&s->ev_start), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
     if (!hip_ok(hipEventCreate(&s->ev_stop), "hipEventCreate")) { (void)hipEventDestroy(s->ev_start); free_scene(s); return CRT_E_HIP; }
+    if (!hip_ok(hipEventCreate(&s->ev_bin), "hipEventCreate")) { (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); free_scene(s); return CRT_E_HIP; }
     s->ev_valid = true;
 
     DevScene& dv = s->dev;
@@ -402,6 +453,13 @@ int crt_scene_set_traverse_mode(crt_scene* s, int mode)
 {
     if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;
     s->mode = mode;
+    return CRT_OK;
+}
+int crt_scene_set_ray_binning(crt_scene* s, int on)
+{
+    if (!s) return CRT_E_INVALID;
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->binning = on != 0;
     return CRT_OK;
 }
 int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
@@ -570,6 +628,19 @@ int crt_scene_reset_counters(crt_scene* s)
     if (!guard.ok) return CRT_E_HIP;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->d_counters, 0, 256));
+    return CRT_OK;
+}
+int crt_scene_last_binning_ms(crt_scene* s, float* ms)
+{
+    if (!s || !ms) return CRT_E_INVALID;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->launched) return CRT_E_INVALID;
+    *ms = 0.0f;
+    if (!s->last_binned) return CRT_OK;
+    HIPCHK(hipEventSynchronize(s->ev_start));
+    HIPCHK(hipEventElapsedTime(ms, s->ev_bin, s->ev_start));
     return CRT_OK;
 }
 int crt_scene_last_kernel_ms(crt_scene* s, float* ms)

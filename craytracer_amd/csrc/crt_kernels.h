@@ -32,6 +32,7 @@ struct LaunchArgs {
     unsigned* ovf_word;           /* [CRT_OVF_DEPTH][grid threads] */
     float* ovf_key;               /* [CRT_OVF_DEPTH][grid threads] */
     unsigned grid_threads;
+    const unsigned* perm;         /* queue slot -> ray index (crt_binning.h), or null: slot == ray index */
 };
 
 /* ---- per-lane stack ----------------------------------------------------------------
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
         if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
             const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
             if (idx != 0xFFFFFFFFu) {
-                ri = idx;
+                ri = la.perm ? la.perm[idx] : idx;
                 ray = load_ray(la.rays, ri);
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
                 const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
         if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
             const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
             if (idx != 0xFFFFFFFFu) {
-                ri = idx;
+                ri = la.perm ? la.perm[idx] : idx;
                 ray = load_ray(la.rays, ri);
                 ld = la.light_dist[ri];
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;

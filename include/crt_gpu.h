@@ -193,6 +193,12 @@ int  crt_scene_get_traverse_mode(const crt_scene* s, int* resolved_mode);
 int  crt_host_alloc(size_t bytes, void** out);
 void crt_host_free(void* p);
 
+/* Ray binning (on by default).  No counterpart in the reference.  For QBVH scenes and batches of
+ * 2^18 rays or more, the library first counting-sorts the ray INDICES by the grid cell of the ray
+ * origin and pulls rays from the queue in that order (better L2 reuse); every ray is traced
+ * exactly as before and its result is written at its own index, so outputs do not change. */
+int  crt_scene_set_ray_binning(crt_scene* s, int on);
+
 /* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose
  * H2D copy, kernel and D2H copy are pipelined on two streams; returns when hits[] is complete. */
 int  crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits);
@@ -226,6 +232,8 @@ int  crt_scene_reset_counters(crt_scene* s);
 /* Duration in milliseconds of the most recent traversal kernel launched through this
  * scene, measured with HIP events on the stream it was launched on (syncs). */
 int  crt_scene_last_kernel_ms(crt_scene* s, float* ms);
+/* Duration of the ray-binning kernels that preceded it (0 when the launch did not bin). */
+int  crt_scene_last_binning_ms(crt_scene* s, float* ms);
 
 const char* crt_strerror(int code);
 const char* crt_last_hip_error(void);               /* text of the last failing HIP call */

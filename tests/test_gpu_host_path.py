@@ -97,3 +97,35 @@ def test_two_host_threads_share_a_scene(setup):
     for t in th:
         t.join()
     assert ol.same_bits(out[0], want[:n]) and ol.same_bits(out[1], want[n:])
+
+
+def test_ray_binning_changes_nothing_but_the_order(setup):
+    """crt_scene_set_ray_binning: same bits with and without, closest and any-hit, on a batch large
+    enough (>= 2^18 rays) for the binning step to run; rays outside the scene box and rays with
+    NaN / inf origins must survive the cell computation."""
+    import torch
+    si, sc, rays = setup
+    n = 1 << 20
+    r = rays[:n].copy()
+    r[:1000, :3] *= 50.0                      # far outside the box
+    r[1000:1010, 0] = np.nan
+    r[1010:1020, 1] = np.inf
+    r[1020:1030, 2] = -np.inf
+    ld = (np.random.default_rng(5).random(n) * 6).astype(np.float32)
+    out = {}
+    for on in (True, False):
+        sc.set_ray_binning(on)
+        d_rays = torch.from_numpy(r).cuda()
+        d_ld = torch.from_numpy(ld).cuda()
+        d_hits = torch.empty((n, 5), dtype=torch.int32, device="cuda")
+        d_t = torch.empty(n, dtype=torch.float32, device="cuda")
+        d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+        sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), None)
+        sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), n, d_t.data_ptr(), d_occ.data_ptr(), None)
+        torch.cuda.synchronize()
+        out[on] = (d_hits.cpu().numpy(), d_t.cpu().numpy(), d_occ.cpu().numpy())
+    sc.set_ray_binning(True)
+    for a, b in zip(out[True], out[False]):
+        assert ol.same_bits(a, b)
+    o = ol.OracleScene(si, api.ACCEL_BVH4)
+    assert ol.same_bits(out[True][0][:2048].view(api.HIT_DTYPE).reshape(-1), o.intersect(r[:2048]))
