@@ -251,8 +251,13 @@ def main():
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file)).get(args.workload + ("/shadow" if shadow else ""))
-            if tr and tr.get("rays") == n:
+            if tr and tr.get("rays") == n and args.binning == "on":
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                # measured fabric bytes (PMC, profiles/traffic.json) over the live kernel time: the
+                # caches serve part of the algorithmic bytes, which is how `frac` can pass 1
+                out["roofline"]["traffic_gbs"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9, 1)
+                out["roofline"]["traffic_frac"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                out["roofline"]["l2_hit_rate"] = tr.get("l2_hit_rate")
         except Exception:
             pass
 
