@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", default="on", choices=["on", "off"],
                     help="the library's ray binning step (inside the timed region); off = arrival order")
+    ap.add_argument("--accel", default="bvh4", choices=["bvh4", "bvh", "grid"],
+                    help="bvh4 = the headline QBVH path; bvh / grid = the reference's other accelerators (extra lines)")
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
     args = ap.parse_args()
@@ -162,7 +164,8 @@ def main():
     t0 = time.time()
     n_copies, n_lat, n_lon = WORKLOADS[args.workload]
     si = scenes.courtyard(n_copies, n_lat, n_lon, seed=5)
-    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    accel = {"bvh4": api.ACCEL_BVH4, "bvh": api.ACCEL_BVH, "grid": api.ACCEL_GRID}[args.accel]
+    built = api.BuiltScene(si, accel)
     sc = api.Scene(built, local_rank)
     sc.set_ray_binning(args.binning == "on")
     build_s = time.time() - t0
@@ -202,9 +205,13 @@ def main():
     # 24 (ray in) + 20 (hit out) + one QBVH node per visit + 36 + 4 per triangle tested.
     # A node visit reads 112 of the node's 128 bytes (6 plane rows + the child words; the axis byte
     # travels in the parent's child word), so 112 is what is charged, not SURVEY's planning value 128.
-    bytes_per_ray = 24 + 20 + 112 * nodes_per_ray + 40 * tris_per_ray
-    if shadow:        # ray + light_dist in, t + occluded out
-        bytes_per_ray = 28 + 5 + 112 * nodes_per_ray + 40 * tris_per_ray
+    io_bytes = 28 + 5 if shadow else 24 + 20          # shadow: ray + light_dist in, t + occluded out
+    if args.accel == "bvh4":
+        bytes_per_ray = io_bytes + 112 * nodes_per_ray + 40 * tris_per_ray
+    elif args.accel == "bvh":                          # 32-byte nodes
+        bytes_per_ray = io_bytes + 32 * nodes_per_ray + 40 * tris_per_ray
+    else:                                              # grid: nodes_visited counts cells walked; 8 B of cell_start
+        bytes_per_ray = io_bytes + 8 * nodes_per_ray + 44 * tris_per_ray   # + 4 B item index per object tested
 
     for _ in range(args.warmup):
         step()
@@ -231,26 +238,29 @@ def main():
     achieved_gbs = bytes_per_ray * n / (avg_kernel_ms * 1e-3) / 1e9
 
     out = {
-        "metric": "Mrays/s any-hit (shadow rays toward an area light), QBVH" if shadow else "Mrays/s closest-hit (incoherent), QBVH",
+        "metric": ("Mrays/s any-hit (shadow rays toward an area light), %s" if shadow else "Mrays/s closest-hit (incoherent), %s")
+        % {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel],
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), QBVH, %d %s per GPU per step"
-                               % (args.workload, n_tris, n, "shadow rays from the incoherent hit points toward a ceiling light"
+        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), %s, %d %s per GPU per step"
+                               % (args.workload, n_tris, args.accel.upper(), n, "shadow rays from the incoherent hit points toward a ceiling light"
                                   if shadow else "incoherent bounce-1..3 rays"),
-                   "triangles": n_tris, "rays_per_gpu": n, "accel": "BVH4", "traverse_mode": "reference order, first hit ends the walk" if shadow else "pruned",
+                   "triangles": n_tris, "rays_per_gpu": n, "accel": args.accel.upper(), "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
+                   if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),
                    "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
                    "scene_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "kernel_ms": round(avg_kernel_ms, 4), "binning_ms": round(float(np.mean(bin_ms)), 4),
+                     "kernel": {"bvh4": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>",
+                                "bvh": "k_bvh2<tri_only>", "grid": "k_grid<tri_only>"}[args.accel], "kernel_ms": round(avg_kernel_ms, 4), "binning_ms": round(float(np.mean(bin_ms)), 4),
                      "bytes_per_ray": round(bytes_per_ray, 2), "nodes_per_ray": round(nodes_per_ray, 3),
                      "tris_per_ray": round(tris_per_ray, 3)},
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file)).get(args.workload + ("/shadow" if shadow else ""))
+            tr = json.load(open(traffic_file)).get(args.workload + ("/shadow" if shadow else "")) if args.accel == "bvh4" else None
             if tr and tr.get("rays") == n and args.binning == "on":
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 # measured fabric bytes (PMC, profiles/traffic.json) over the live kernel time: the
@@ -265,7 +275,7 @@ def main():
         # the CPU checker timed as "the reference's path on the host cores": same tree, same rays
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as ol
-        o = ol.OracleScene(si, built=built)
+        o = ol.OracleScene(si, accel, built=built)
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         host_rays = d_rays.cpu().numpy()
         host_ld = d_ld.cpu().numpy() if shadow else None

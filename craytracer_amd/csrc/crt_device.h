@@ -41,7 +41,9 @@ struct DevScene {
     int nng;                        /* num_non_grid_obj */
     int n_accel;                    /* num_obj - nng */
     int accel;
-    unsigned root_word;             /* child-word form of the QBVH root: axis2(root) << 28 | 0 */
+    unsigned root_word;             /* QBVH: axis2(root) << 28 | 0;  BVH: child-word form of the root */
+    const float4* bnodes2;          /* BVH: 64-byte inner-node records for k_bvh2 (see crt_kernels.h) */
+    float root_bmin[3], root_bmax[3];
 };
 
 #define CRT_LEAF_BIT 0x80000000u
@@ -99,6 +101,29 @@ CRT_DEV float dev_ray_aabb(const float* bmin, const float* bmax, const DRay& ray
     if (b >= 0) { ty_min = (bmin[1] - ray.oy) * b; ty_max = (bmax[1] - ray.oy) * b; }
     else        { ty_min = (bmax[1] - ray.oy) * b; ty_max = (bmin[1] - ray.oy) * b; }
     float c = 1.0f / ray.dz;
+    if (c >= 0) { tz_min = (bmin[2] - ray.oz) * c; tz_max = (bmax[2] - ray.oz) * c; }
+    else        { tz_min = (bmax[2] - ray.oz) * c; tz_max = (bmin[2] - ray.oz) * c; }
+    float t0, t1;
+    if (tx_min > ty_min) t0 = tx_min; else t0 = ty_min;
+    if (tz_min > t0) t0 = tz_min;
+    if (tx_max < ty_max) t1 = tx_max; else t1 = ty_max;
+    if (tz_max < t1) t1 = tz_max;
+    *t0_out = t0;
+    if (t0 < t1 && t1 > CRT_K_EPSILON) {
+        if (t0 > CRT_K_EPSILON) return t0;
+        return t1;
+    }
+    return CRT_TMAX;
+}
+
+/* the same with the three reciprocals taken once per ray (they do not depend on the box) */
+CRT_DEV float dev_ray_aabb_inv(const float* bmin, const float* bmax, const DRay& ray, float a, float b, float c, float* t0_out)
+{
+    float tx_min, ty_min, tz_min, tx_max, ty_max, tz_max;
+    if (a >= 0) { tx_min = (bmin[0] - ray.ox) * a; tx_max = (bmax[0] - ray.ox) * a; }
+    else        { tx_min = (bmax[0] - ray.ox) * a; tx_max = (bmin[0] - ray.ox) * a; }
+    if (b >= 0) { ty_min = (bmin[1] - ray.oy) * b; ty_max = (bmax[1] - ray.oy) * b; }
+    else        { ty_min = (bmax[1] - ray.oy) * b; ty_max = (bmin[1] - ray.oy) * b; }
     if (c >= 0) { tz_min = (bmin[2] - ray.oz) * c; tz_max = (bmax[2] - ray.oz) * c; }
     else        { tz_min = (bmax[2] - ray.oz) * c; tz_max = (bmin[2] - ray.oz) * c; }
     float t0, t1;

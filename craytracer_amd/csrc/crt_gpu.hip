@@ -48,7 +48,7 @@ struct crt_scene {
     bool count;
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_cell_start; void* d_cell_items;
+    void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
     unsigned long long* d_counters;
     unsigned* d_queue_head;   /* 256 B, word 0 used */
     unsigned* d_ovf_word; float* d_ovf_key; unsigned ovf_threads;
@@ -63,6 +63,7 @@ struct crt_scene {
     void* d_chunk_in[2]; void* d_chunk_aux[2]; void* d_chunk_out[2]; void* d_chunk_out2[2];
     size_t chunk_cap;         /* rays per chunk buffer */
     /* ray binning (crt_binning.h): triangle-only QBVH scenes, batches of at least CRT_BIN_MIN_RAYS */
+    unsigned root_word2;      /* BVH: root in k_bvh2's child-word form */
     bool binning; BinGrid bin_grid; bool bin_grid_valid;
     unsigned* d_bin_hist; unsigned* d_bin_cursor; unsigned* d_perm; size_t perm_cap;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
@@ -185,7 +186,7 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
-                     s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key,
+                     s->d_bnodes2, s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key,
                      s->d_bin_hist, s->d_bin_cursor, s->d_perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
@@ -253,7 +254,7 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest_exact<TRI_ONLY, COUNT>, la, st)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT>, la, st, true);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, false>, la, st)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false>, la, st);
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st);
     default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st);
     }
@@ -265,7 +266,7 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, true>, la, st)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true>, la, st);
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
     default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
     }
@@ -336,7 +337,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         }
         s->tri_only = all_tri;
         s->accel_tri_only = accel_tri;
-        if (desc->accel == CRT_ACCEL_BVH4 && n - nng > 0) {          /* box of the triangles under the accelerator */
+        if ((desc->accel == CRT_ACCEL_BVH4 || desc->accel == CRT_ACCEL_BVH) && n - nng > 0) {   /* box of the triangles under the accelerator */
             float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
             bool any = false;
             for (int i = nng; i < n; i++) {
@@ -389,6 +390,33 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 n2[(size_t)i*2 + 1] = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], rf);
             }
         }
+        /* k_bvh2's layout: inner nodes only, renumbered in index order, each with both child boxes */
+        std::vector<float4> b2;
+        if (desc->accel == CRT_ACCEL_BVH && desc->num_nodes2 > 0) {
+            std::vector<int> inner_id((size_t)desc->num_nodes2, -1);
+            int n_inner = 0;
+            for (int i = 0; i < desc->num_nodes2; i++) if (desc->nodes2[i].left >= 0) inner_id[i] = n_inner++;
+            auto word = [&](int node) -> unsigned {
+                const crt_bvh2_node& c = desc->nodes2[node];
+                return c.left < 0 ? (CRT_LEAF_BIT | (unsigned)c.right) : (unsigned)inner_id[node];
+            };
+            b2.resize((size_t)n_inner * 4);
+            for (int i = 0; i < desc->num_nodes2; i++) {
+                const crt_bvh2_node& nd = desc->nodes2[i];
+                if (nd.left < 0) continue;
+                const crt_bvh2_node& l = desc->nodes2[nd.left];
+                const crt_bvh2_node& r = desc->nodes2[nd.right];
+                const unsigned lw = word(nd.left), rw = word(nd.right);
+                float lf, rf; memcpy(&lf, &lw, 4); memcpy(&rf, &rw, 4);
+                float4* q = &b2[(size_t)inner_id[i] * 4];
+                q[0] = make_float4(l.bmin[0], l.bmin[1], l.bmin[2], l.bmax[0]);
+                q[1] = make_float4(l.bmax[1], l.bmax[2], r.bmin[0], r.bmin[1]);
+                q[2] = make_float4(r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]);
+                q[3] = make_float4(lf, rf, 0.0f, 0.0f);
+            }
+            s->root_word2 = word(0);
+            for (int a = 0; a < 3; a++) { s->dev.root_bmin[a] = desc->nodes2[0].bmin[a]; s->dev.root_bmax[a] = desc->nodes2[0].bmax[a]; }
+        }
         std::vector<crt_shape> shapes;
         if (desc->num_shapes > 0) shapes.assign(desc->shapes, desc->shapes + desc->num_shapes);
         std::vector<int32_t> cs, ci;
@@ -398,7 +426,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         }
 
         if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK ||
-            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
+            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK) {
             free_scene(s);
             return rc;
@@ -437,6 +465,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.grid = desc->grid;
     dv.num_obj = n; dv.nng = nng; dv.n_accel = n - nng; dv.accel = desc->accel;
     dv.root_word = (desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0) ? ((unsigned)(desc->nodes4[0].axis & 0x03) << 28) : 0u;
+    if (desc->accel == CRT_ACCEL_BVH) dv.root_word = s->root_word2;
+    dv.bnodes2 = (const float4*)s->d_bnodes2;
     *out = s;
     return CRT_OK;
 }

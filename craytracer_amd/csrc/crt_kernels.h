@@ -588,80 +588,105 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
  * its entry t0 (> eps) lies strictly beyond the nearest hit.  SHADOW = true gives
  * BVHShadowIntersectTest (intersect.h:344-362): min t over the tree, light_dist unused.
  * ===================================================================================== */
+/* Device layout (crt_gpu.hip): one 64-byte record per INNER node holding both children's boxes and
+ * child words, so a visit is one 64-byte read and leaves are never loaded:
+ *   q0 = lmin.xyz lmax.x   q1 = lmax.yz rmin.xy   q2 = rmin.z rmax.xyz   q3 = left word, right word
+ *   word = inner-record index, or CRT_LEAF_BIT | object index (final order).
+ * Lanes are refilled from the queue as in k_bvh4_closest. */
 template <bool TRI_ONLY, bool COUNT, bool SHADOW>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
-    const unsigned lane = threadIdx.x & 63;
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
     st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
     st.ovf_stride = la.grid_threads;
+    st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
     const float ninf = -__builtin_huge_valf();
 
+    bool alive = false, queue_empty = false, walking = false;
+    unsigned ri = 0, cur = 0;
+    DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
+    float ia = 1.0f, ib = 1.0f, ic = 1.0f;
+    float best_t = CRT_TMAX;
+    DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
-        if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
-            const DRay ray = load_ray(la.rays, ri);
-            float best_t = CRT_TMAX;
-            DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
-            st.sp = 0;
-            bool alive = false;
-            unsigned cur = 0;
-            if (sc.n_accel > 0) {                                   /* root box, intersect.h:381,:454 */
-                const float4 a = sc.nodes2[0], b = sc.nodes2[1];
-                float bmin[3] = { a.x, a.y, a.z }, bmax[3] = { b.x, b.y, b.z }, t0;
-                if (COUNT) c_nodes++;
-                alive = dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX;
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
+            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
+            if (idx != 0xFFFFFFFFu) {
+                ri = la.perm ? la.perm[idx] : idx;
+                ray = load_ray(la.rays, ri);
+                ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* aabb.cpp:94,:106,:118 */
+                best_t = CRT_TMAX;
+                best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+                st.sp = 0;
+                cur = sc.root_word;
+                walking = false;
+                if (sc.n_accel > 0) {                                                  /* root box, intersect.h:381,:454 */
+                    float t0;
+                    if (COUNT) c_nodes++;
+                    walking = dev_ray_aabb_inv(sc.root_bmin, sc.root_bmax, ray, ia, ib, ic, &t0) < CRT_TMAX;
+                }
+                alive = true;
             }
-            while (alive) {
-                const float4 a = sc.nodes2[(size_t)cur * 2], b = sc.nodes2[(size_t)cur * 2 + 1];
-                const int left = __float_as_int(a.w), right = __float_as_int(b.w);
-                if (left < 0) {
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive) {
+            if (walking) {
+                bool need_pop = true;
+                if (cur & CRT_LEAF_BIT) {
                     DHit h;
-                    const float t = dev_object<TRI_ONLY>(sc, right, ray, SHADOW, &h);
+                    const float t = dev_object<TRI_ONLY>(sc, (int)(cur & ~CRT_LEAF_BIT), ray, SHADOW, &h);
                     if (COUNT) c_prims++;
                     if (SHADOW) { if (t < best_t) best_t = t; }
-                    else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }
+                    else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
                 } else {
-                    const float4 la0 = sc.nodes2[(size_t)left * 2], la1 = sc.nodes2[(size_t)left * 2 + 1];
-                    const float4 ra0 = sc.nodes2[(size_t)right * 2], ra1 = sc.nodes2[(size_t)right * 2 + 1];
+                    const float4* nd = sc.bnodes2 + (size_t)cur * 4;
+                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                     if (COUNT) c_nodes += 2;
-                    float lmin[3] = { la0.x, la0.y, la0.z }, lmax[3] = { la1.x, la1.y, la1.z };
-                    float rmn[3] = { ra0.x, ra0.y, ra0.z }, rmx[3] = { ra1.x, ra1.y, ra1.z };
+                    const float lmin[3] = { q0.x, q0.y, q0.z }, lmax[3] = { q0.w, q1.x, q1.y };
+                    const float rmn[3] = { q1.z, q1.w, q2.x }, rmx[3] = { q2.y, q2.z, q2.w };
                     float lt0, rt0;
-                    const float lbt = dev_ray_aabb(lmin, lmax, ray, &lt0);
-                    const float rbt = dev_ray_aabb(rmn, rmx, ray, &rt0);
+                    const float lbt = dev_ray_aabb_inv(lmin, lmax, ray, ia, ib, ic, &lt0);
+                    const float rbt = dev_ray_aabb_inv(rmn, rmx, ray, ia, ib, ic, &rt0);
                     const float lkey = lt0 > CRT_K_EPSILON ? lt0 : ninf;
                     const float rkey = rt0 > CRT_K_EPSILON ? rt0 : ninf;
                     const bool lv = lbt < CRT_TMAX && !(lkey > best_t);
                     const bool rv = rbt < CRT_TMAX && !(rkey > best_t);
-                    if (rv) st.push((unsigned)right, rkey);
-                    if (lv) { cur = (unsigned)left; continue; }
+                    const unsigned lw = __float_as_uint(q3.x), rw = __float_as_uint(q3.y);
+                    if (lv) {
+                        if (rv) st.push(rw, rkey);
+                        cur = lw; need_pop = false;
+                    } else if (rv) { cur = rw; need_pop = false; }
                 }
+                if (need_pop) {
+                    walking = false;
+                    while (st.sp > 0) {
+                        unsigned w; float key;
+                        st.pop(&w, &key);
+                        if (!(key > best_t)) { cur = w; walking = true; break; }
+                    }
+                }
+            }
+            if (!walking) {
+                if (!SHADOW) {
+                    linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                    store_hit(la.hits, ri, best_t, best);
+                } else {
+                    const float ld = la.light_dist[ri];
+                    float t = best_t;
+                    if (t >= ld) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, t, &c_prims);   /* intersect.h:458-468 */
+                    if (la.t_out) la.t_out[ri] = t;
+                    if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+                }
+                if (COUNT) c_rays++;
                 alive = false;
-                while (st.sp > 0) {
-                    unsigned w; float key;
-                    st.pop(&w, &key);
-                    if (!(key > best_t)) { cur = w; alive = true; break; }
-                }
             }
-            if (!SHADOW) {
-                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-                store_hit(la.hits, ri, best_t, best);
-            } else {
-                const float ld = la.light_dist[ri];
-                float t = best_t;
-                if (t >= ld) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, t, &c_prims);   /* intersect.h:458-468 */
-                if (la.t_out) la.t_out[ri] = t;
-                if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
-            }
-            if (COUNT) c_rays++;
         }
     }
     flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);

@@ -183,3 +183,40 @@ def test_any_hit_oracle_on_a_sample(case):
     assert np.array_equal(d_occ.cpu().numpy().astype(bool), occ)
     assert 0.02 < occ.mean() < 0.98
     assert cnt["nodes_visited"] == oc["nodes_visited"] and cnt["prims_tested"] == oc["prims_tested"]
+
+
+@pytest.mark.parametrize("accel", [api.ACCEL_BVH, api.ACCEL_GRID])
+def test_other_accelerators_at_1m_triangles(accel):
+    """Binary BVH and uniform grid on the ~1M-triangle scene, 2^20 incoherent rays: the oracle on a
+    sample (pruned walk for the BVH on 2^17 rays, the reference's full walk on 2^13), every ray's t
+    against the QBVH result (same triangles, same intersector: t is accelerator-independent; ids may
+    differ only on exact-t ties, where the BVH keeps the later and the others the earlier object)."""
+    import torch
+    import bench
+    si = scenes.buddha_like(512, 1024, seed=3)
+    n = 1 << 20
+    dev = torch.device("cuda", 0)
+    q = api.Scene(api.BuiltScene(si, api.ACCEL_BVH4), 0)
+    d_rays = bench.gen_incoherent_rays(q, si, n, 0xC0FFEE, dev)
+    rays = d_rays.cpu().numpy()
+    ref4 = q.intersect(rays)
+    q.close()
+    built = api.BuiltScene(si, accel)
+    sc = api.Scene(built, 0)
+    hits = sc.intersect(rays)
+    ld = np.where(ref4["obj"] >= 0, ref4["t"] * np.float32(1.5), np.float32(10.0)).astype(np.float32)
+    st, occ = sc.shadow(rays, ld)
+    sc.close()
+    nz = (rays[:, 3:] != 0).all(1)                    # the grid's NaN flow (class T2) is checked against the oracle below
+    assert ol.same_bits(hits["t"][nz], ref4["t"][nz])
+    differ = hits["obj"] != ref4["obj"]
+    assert differ.mean() < 1e-3 and (hits["t"][differ] == ref4["t"][differ]).all()
+    o = ol.OracleScene(si, accel, built=built)
+    threads = min(os.cpu_count() or 1, 16)
+    m = 1 << 17
+    if accel == api.ACCEL_BVH:
+        assert ol.same_bits(hits[:m], o.intersect(rays[:m], mode=api.TRAVERSE_PRUNED, nthreads=threads))
+        m = 1 << 13
+    assert ol.same_bits(hits[:m], o.intersect(rays[:m], mode=api.TRAVERSE_EXACT, nthreads=threads))
+    wt, wocc = o.shadow(rays[:m], ld[:m], nthreads=threads)
+    assert ol.same_bits(st[:m], wt) and np.array_equal(occ[:m], wocc)
