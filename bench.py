@@ -268,6 +268,13 @@ def main():
                 out["roofline"]["traffic_gbs"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9, 1)
                 out["roofline"]["traffic_frac"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 out["roofline"]["l2_hit_rate"] = tr.get("l2_hit_rate")
+                if tr.get("tcp_lane_accesses_per_launch"):
+                    # the measured limiter: the L1 serves 1.0 lane-divergent access per clock per CU
+                    props = torch.cuda.get_device_properties(device)
+                    clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+                    out["roofline"]["l1_lane_access_per_clk"] = round(
+                        tr["tcp_lane_accesses_per_launch"] / (avg_kernel_ms * 1e-3) / clk_hz / props.multi_processor_count, 3)
+                    out["roofline"]["l1_lane_access_peak"] = 1.0
         except Exception:
             pass
 
