@@ -73,6 +73,17 @@ class CrtSceneDesc(C.Structure):
                 ("grid", CrtGrid), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p)]
 
 
+class CrtCamera(C.Structure):
+    _fields_ = [("type", C.c_int32), ("focal_pt_dist", C.c_float), ("focal_length", C.c_float), ("lens_radius", C.c_float),
+                ("position", C.c_float * 3), ("x_axis", C.c_float * 3), ("y_axis", C.c_float * 3), ("z_axis", C.c_float * 3),
+                ("focal_point", C.c_float * 3)]
+
+
+class CrtFilm(C.Structure):
+    _fields_ = [("fov", C.c_float), ("frame_length", C.c_float), ("frame_height", C.c_float), ("pixel_length", C.c_float),
+                ("frame_res_width", C.c_int32), ("frame_res_height", C.c_int32)]
+
+
 class CrtCounters(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
@@ -84,6 +95,7 @@ EXPORTS = [
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
     "crt_host_alloc", "crt_host_free",
+    "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
@@ -122,6 +134,12 @@ def lib():
     L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
     L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.crt_scene_set_ray_binning.argtypes = [vp, C.c_int]
+    f3 = C.POINTER(C.c_float)
+    L.crt_camera_init.argtypes = [C.POINTER(CrtCamera), C.c_int, C.c_float, C.c_float]
+    L.crt_camera_look_at.argtypes = [C.POINTER(CrtCamera), f3, f3, f3]
+    L.crt_camera_set_focal_dist.argtypes = [C.POINTER(CrtCamera), C.c_float]
+    L.crt_film_dimension.argtypes = [C.POINTER(CrtFilm), C.c_float, C.c_int, C.c_int, C.POINTER(CrtCamera)]
+    L.crt_primary_rays_dev.argtypes = [C.c_int, C.POINTER(CrtCamera), C.POINTER(CrtFilm), C.c_uint32, C.c_size_t, vp, vp, vp, vp]
     L.crt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.crt_host_free.argtypes = [vp]
     L.crt_host_free.restype = None
@@ -160,6 +178,38 @@ def _check(code, where):
 
 def _ptr(a):
     return a.ctypes.data if a is not None and a.size else None
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def make_camera(position, look_point, up=(0.0, 1.0, 0.0), focal_pt_dist=None, thin_lens=None, L=None):
+    """Camera set up as the scene loader does (scenefile.h camera block): init, optional focal
+    distance, look-at.  thin_lens = (focal_length, lens_radius) or None for a pinhole.
+    L: library to call (default: the GPU library; tests pass the oracle / reference build)."""
+    L = L or lib()
+    cam = CrtCamera()
+    if thin_lens:
+        _check(L.crt_camera_init(C.byref(cam), 1, float(thin_lens[0]), float(thin_lens[1])), "crt_camera_init")
+    else:
+        _check(L.crt_camera_init(C.byref(cam), 0, 0.0, 0.0), "crt_camera_init")
+    if focal_pt_dist is not None:
+        _check(L.crt_camera_set_focal_dist(C.byref(cam), float(focal_pt_dist)), "crt_camera_set_focal_dist")
+    _check(L.crt_camera_look_at(C.byref(cam), _f3(position), _f3(look_point), _f3(up)), "crt_camera_look_at")
+    return cam
+
+
+def make_film(cam, fov, width, height, L=None):
+    L = L or lib()
+    film = CrtFilm()
+    _check(L.crt_film_dimension(C.byref(film), float(fov), int(width), int(height), C.byref(cam)), "crt_film_dimension")
+    return film
+
+
+def primary_rays_dev(cam, film, first_pixel, n, d_rays, d_image_samples=None, d_lens_samples=None, device=0, stream=None):
+    _check(lib().crt_primary_rays_dev(device, C.byref(cam), C.byref(film), first_pixel, n, d_image_samples, d_lens_samples,
+                                      d_rays, stream), "crt_primary_rays_dev")
 
 
 class HostBuffer:

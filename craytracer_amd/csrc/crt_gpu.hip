@@ -8,6 +8,7 @@
  */
 #include "crt_kernels.h"
 #include "crt_binning.h"
+#include "crt_camera.h"
 
 #include <string.h>
 #include <stdio.h>
@@ -632,6 +633,58 @@ int crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist,
     for (int j = 0; j < 2; j++)
         if (s->chunk_streams_valid && !hip_ok(hipStreamSynchronize(s->chunk_stream[j]), "hipStreamSynchronize") && rc == CRT_OK) rc = CRT_E_HIP;
     return rc;
+}
+
+/* ---- primary rays ------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_primary_rays(crt_camera cam, crt_film film, unsigned first_pixel, unsigned n,
+                                                      const float2* image_samples, const float2* lens_samples, crt_ray* rays)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float2 is = image_samples ? image_samples[i] : make_float2(0.5f, 0.5f);
+    const float2 ls = lens_samples ? lens_samples[i] : make_float2(0.5f, 0.5f);
+    crt_ray r;
+    cam_primary_ray(&r, cam, film, first_pixel + i, is.x, is.y, ls.x, ls.y);
+    float2* out = reinterpret_cast<float2*>(rays + i);
+    out[0] = make_float2(r.o[0], r.o[1]); out[1] = make_float2(r.o[2], r.d[0]); out[2] = make_float2(r.d[1], r.d[2]);
+}
+
+int crt_camera_init(crt_camera* cam, int type, float focal_length, float lens_radius)
+{
+    if (!cam || type < 0 || type > 1) return CRT_E_INVALID;
+    cam_init(cam, type, focal_length, lens_radius);
+    return CRT_OK;
+}
+int crt_camera_look_at(crt_camera* cam, const float position[3], const float look_point[3], const float up[3])
+{
+    if (!cam || !position || !look_point || !up) return CRT_E_INVALID;
+    cam_look_at(cam, position, look_point, up);
+    return CRT_OK;
+}
+int crt_camera_set_focal_dist(crt_camera* cam, float focal_pt_dist)
+{
+    if (!cam) return CRT_E_INVALID;
+    cam_set_focal_dist(cam, focal_pt_dist);
+    return CRT_OK;
+}
+int crt_film_dimension(crt_film* film, float fov, int res_width, int res_height, const crt_camera* cam)
+{
+    if (!film || !cam || res_width < 1 || res_height < 1) return CRT_E_INVALID;
+    cam_film_dimension(film, fov, res_width, res_height, cam);
+    return CRT_OK;
+}
+int crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* film, uint32_t first_pixel, size_t n,
+                         const float* d_image_samples, const float* d_lens_samples, crt_ray* d_rays, void* stream)
+{
+    if (!cam || !film || (n > 0 && !d_rays) || film->frame_res_width < 1 || cam->type < 0 || cam->type > 1) return CRT_E_INVALID;
+    if (n == 0) return CRT_OK;
+    if (n > 0xFFFFFF00u || (unsigned long long)first_pixel + n > 0xFFFFFFFFull) return CRT_E_TOOBIG;
+    DeviceGuard guard(device);
+    if (!guard.ok) return CRT_E_HIP;
+    hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cam, *film,
+                       (unsigned)first_pixel, (unsigned)n, (const float2*)d_image_samples, (const float2*)d_lens_samples, d_rays);
+    HIPCHK(hipGetLastError());
+    return CRT_OK;
 }
 
 int crt_scene_enable_counters(crt_scene* s, int on)

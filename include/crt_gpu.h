@@ -217,6 +217,35 @@ int  crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_
 int  crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                           float* d_t_out, uint8_t* d_occluded_out, void* stream);
 
+/* ---- primary rays ------------------------------------------- */
+/* Camera (camera.h:14-26) without its sample table, and the Film fields the ray set-up reads
+ * (camera.h:44-52).  Same field meaning as the reference. */
+typedef struct crt_camera {
+    int32_t type;                 /* CameraType: 0 Pinhole, 1 ThinLens (camera.h:8-12) */
+    float   focal_pt_dist, focal_length, lens_radius;
+    float   position[3], x_axis[3], y_axis[3], z_axis[3], focal_point[3];
+} crt_camera;
+typedef struct crt_film {
+    float   fov;
+    float   frame_length, frame_height, pixel_length;
+    int32_t frame_res_width, frame_res_height;
+} crt_film;
+
+/* Host-side set-up, as the reference does it once per scene:
+ * initPinholeCameraDefault / initThinLensCameraDefault geometry (camera.cpp:21-51),
+ * cameraLookAt (camera.cpp:53-67), setFocalDist (:70-76), calcFilmDimension (:143-148). */
+int  crt_camera_init(crt_camera* cam, int type, float focal_length, float lens_radius);
+int  crt_camera_look_at(crt_camera* cam, const float position[3], const float look_point[3], const float up[3]);
+int  crt_camera_set_focal_dist(crt_camera* cam, float focal_pt_dist);
+int  crt_film_dimension(crt_film* film, float fov, int res_width, int res_height, const crt_camera* cam);
+
+/* n x { calcImageCoord (camera.cpp:151-157); calcCameraRay (:130-141) } for pixels
+ * first_pixel .. first_pixel + n - 1 (pixel_index as in main.cpp:100-115), on `device`.
+ * d_image_samples / d_lens_samples: [n][2] floats on the device (the two Sampler_getSample
+ * values of main.cpp:107,:112), or NULL for (0.5, 0.5).  Enqueued on `stream`, no sync. */
+int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* film, uint32_t first_pixel, size_t n,
+                          const float* d_image_samples, const float* d_lens_samples, crt_ray* d_rays, void* stream);
+
 /* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)
  * and g_intersect_count (shapes.cpp:3).  Counting is off by default (it costs atomics);
  * when on, kernels add per-ray node / primitive-test counts. */

@@ -1532,3 +1532,91 @@ float oracle_ray_aabb(const float bmin[3], const float bmax[3], const crt_ray* r
 }
 
 } // extern "C"
+
+/* ---- primary rays: camera.cpp of the reference, restated (test infrastructure) ---------- */
+namespace {
+inline void cNormalize(float* r, const float* a)                   /* util/vec.h:206-215 */
+{
+    float length = (float)sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
+    if (length == 0) { r[0] = r[1] = r[2] = 0.0f; return; }
+    float inv = 1.0f / length;
+    r[0] = a[0] * inv; r[1] = a[1] * inv; r[2] = a[2] * inv;
+}
+inline void cCross(float* r, const float* a, const float* b)       /* util/vec.h:228-233 */
+{
+    r[0] = a[1]*b[2] - a[2]*b[1]; r[1] = a[2]*b[0] - a[0]*b[2]; r[2] = a[0]*b[1] - a[1]*b[0];
+}
+}
+extern "C" {
+void oracle_camera_init(crt_camera* c, int type, float focal_length, float lens_radius)
+{   /* initPinholeCameraDefault / initThinLensCameraDefault, camera.cpp:21-51 (sample table not needed here) */
+    for (int k = 0; k < 3; k++) { c->position[k] = 0.0f; c->x_axis[k] = (k == 0); c->y_axis[k] = (k == 1); c->z_axis[k] = (k == 2); }
+    c->focal_pt_dist = 0.035f;
+    c->focal_point[0] = 0.0f; c->focal_point[1] = 0.0f; c->focal_point[2] = c->focal_pt_dist;
+    c->type = 0; c->focal_length = 0.0f; c->lens_radius = 0.0f;
+    if (type == 1) { c->type = 1; c->focal_length = focal_length; c->lens_radius = lens_radius; }
+}
+void oracle_camera_look_at(crt_camera* c, const float* position, const float* look_point, const float* up)
+{   /* cameraLookAt, camera.cpp:53-67 */
+    float v[3], look_vec[3], x[3], disp[3];
+    for (int k = 0; k < 3; k++) v[k] = look_point[k] - position[k];
+    cNormalize(look_vec, v);
+    for (int k = 0; k < 3; k++) c->z_axis[k] = -look_vec[k];
+    cCross(x, c->z_axis, up);
+    cNormalize(c->x_axis, x);
+    for (int k = 0; k < 3; k++) c->x_axis[k] = -c->x_axis[k];
+    cCross(c->y_axis, c->z_axis, c->x_axis);
+    for (int k = 0; k < 3; k++) disp[k] = c->z_axis[k] * c->focal_pt_dist;
+    for (int k = 0; k < 3; k++) c->focal_point[k] = position[k] + disp[k];
+    for (int k = 0; k < 3; k++) c->position[k] = position[k];
+}
+void oracle_camera_set_focal_dist(crt_camera* c, float d)
+{   /* setFocalDist, camera.cpp:70-76 */
+    c->focal_pt_dist = d;
+    for (int k = 0; k < 3; k++) c->focal_point[k] = c->position[k] + c->z_axis[k] * d;
+}
+void oracle_film_dimension(crt_film* f, float fov, int w, int h, const crt_camera* c)
+{   /* calcFilmDimension, camera.cpp:143-148 */
+    f->fov = fov; f->frame_res_width = w; f->frame_res_height = h;
+    f->frame_length = 2.0f * (sin(f->fov/2.0f) * c->focal_pt_dist);
+    f->frame_height = f->frame_length * (float)(f->frame_res_height)/(float)(f->frame_res_width);
+    f->pixel_length = (float)(f->frame_length)/(float)(f->frame_res_width);
+}
+void oracle_primary_rays(const crt_camera* c, const crt_film* f, unsigned first_pixel, size_t n,
+                         const float* image_samples, const float* lens_samples, crt_ray* rays)
+{
+    for (size_t i = 0; i < n; i++) {
+        const int pixel_index = (int)(first_pixel + i);
+        const float s0 = image_samples ? image_samples[2*i] : 0.5f, s1 = image_samples ? image_samples[2*i+1] : 0.5f;
+        const float l0 = lens_samples ? lens_samples[2*i] : 0.5f, l1 = lens_samples ? lens_samples[2*i+1] : 0.5f;
+        float ic[2];                                                /* calcImageCoord, camera.cpp:151-157 */
+        ic[0] = -f->frame_length/2 + f->pixel_length * ((float)(pixel_index % f->frame_res_width) + s0);
+        ic[1] = f->frame_height/2 - f->pixel_length * ((float)(pixel_index / f->frame_res_width) + s1);
+        crt_ray* ray = rays + i;
+        if (c->type == 0) {                                         /* calcRayPinhole, camera.cpp:79-91 */
+            float t1[3], t2[3], loc[3], fp[3], d[3];
+            for (int k = 0; k < 3; k++) t1[k] = c->x_axis[k] * ic[0];
+            for (int k = 0; k < 3; k++) t2[k] = c->y_axis[k] * ic[1];
+            for (int k = 0; k < 3; k++) loc[k] = t1[k] + t2[k];
+            for (int k = 0; k < 3; k++) fp[k] = c->z_axis[k] * c->focal_pt_dist;
+            for (int k = 0; k < 3; k++) d[k] = loc[k] - fp[k];
+            cNormalize(ray->d, d);
+            for (int k = 0; k < 3; k++) ray->o[k] = loc[k] + c->position[k];
+        } else {                                                    /* calcRayThinLens, camera.cpp:94-128 */
+            float phi = 2.0f * M_PI * l0;                           /* mapSampleToDisk, sampling.cpp:606-612 */
+            float radius = sqrtf(l1);
+            float disk[2] = { cosf(phi) * radius, sinf(phi) * radius };
+            float pv[3] = { ic[0], ic[1], 0.0f };
+            float fpp[3] = { pv[0] * (c->focal_length/c->focal_pt_dist), pv[1] * (c->focal_length/c->focal_pt_dist), -c->focal_length };
+            float o[3] = { disk[0] * c->lens_radius, disk[1] * c->lens_radius, c->focal_pt_dist };
+            float d[3] = { fpp[0] - o[0], fpp[1] - o[1], fpp[2] - o[2] }, dn[3];
+            cNormalize(dn, d);
+            float a[3], b[3], e[3];
+            for (int k = 0; k < 3; k++) { a[k] = c->x_axis[k] * dn[0]; b[k] = c->y_axis[k] * dn[1]; e[k] = c->z_axis[k] * dn[2]; }
+            for (int k = 0; k < 3; k++) { a[k] = a[k] + b[k]; ray->d[k] = a[k] + e[k]; }
+            for (int k = 0; k < 3; k++) { a[k] = c->x_axis[k] * o[0]; b[k] = c->y_axis[k] * o[1]; e[k] = c->z_axis[k] * o[2]; }
+            for (int k = 0; k < 3; k++) { a[k] = a[k] + b[k]; a[k] = a[k] + e[k]; ray->o[k] = a[k] + c->position[k]; }
+        }
+    }
+}
+} // extern "C"

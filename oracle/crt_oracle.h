@@ -54,6 +54,14 @@ float oracle_intersect_object(const oracle_scene* s, int final_index, const crt_
 float oracle_shadow_object(const oracle_scene* s, int final_index, const crt_ray* ray);
 float oracle_ray_aabb(const float bmin[3], const float bmax[3], const crt_ray* ray);
 
+/* primary rays: camera.cpp restated (checker for crt_camera_* / crt_primary_rays_dev) */
+void oracle_camera_init(crt_camera* c, int type, float focal_length, float lens_radius);
+void oracle_camera_look_at(crt_camera* c, const float* position, const float* look_point, const float* up);
+void oracle_camera_set_focal_dist(crt_camera* c, float d);
+void oracle_film_dimension(crt_film* f, float fov, int w, int h, const crt_camera* c);
+void oracle_primary_rays(const crt_camera* c, const crt_film* f, unsigned first_pixel, size_t n,
+                         const float* image_samples, const float* lens_samples, crt_ray* rays);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@
 #include "shapes/instanced.h"
 #include "aabb.h"
 #include "util/math.h"
+#include "camera.h"
 
 #include <vector>
 #include <unordered_map>
@@ -416,6 +417,60 @@ REF_API void ref_ray_aabb4(const float bbox[24], const crt_ray* ray, float t_out
     _mm_store_ps(res, tmp);
     for (int i = 0; i < 4; i++) { t_out[i] = res[i]; less_than_out[i] = lt[i] ? 1 : 0; }
 }
+/* ---- primary rays: the reference's own camera.cpp ---------------------------------------- */
+static void cam_to_abi(crt_camera* o, const Camera& c)
+{
+    o->type = (int)c.camera_type; o->focal_pt_dist = c.focal_pt_dist; o->focal_length = c.focal_length; o->lens_radius = c.lens_radius;
+    for (int k = 0; k < 3; k++) { o->position[k] = c.position[k]; o->x_axis[k] = c.x_axis[k]; o->y_axis[k] = c.y_axis[k];
+                                  o->z_axis[k] = c.z_axis[k]; o->focal_point[k] = c.focal_point[k]; }
+}
+static void cam_from_abi(Camera* c, const crt_camera* o)
+{
+    c->camera_type = (CameraType)o->type; c->focal_pt_dist = o->focal_pt_dist; c->focal_length = o->focal_length; c->lens_radius = o->lens_radius;
+    for (int k = 0; k < 3; k++) { c->position[k] = o->position[k]; c->x_axis[k] = o->x_axis[k]; c->y_axis[k] = o->y_axis[k];
+                                  c->z_axis[k] = o->z_axis[k]; c->focal_point[k] = o->focal_point[k]; }
+    c->samples = NULL;
+}
+/* init (pinhole or thin lens) -> optional setFocalDist -> cameraLookAt, all by the reference's functions */
+REF_API void ref_camera_setup(crt_camera* out, int type, float focal_length, float lens_radius, float focal_pt_dist,
+                              const float* position, const float* look_point, const float* up)
+{
+    Camera c;
+    if (type == 1) initThinLensCameraDefault(&c, focal_length, lens_radius, 0, 0);
+    else initPinholeCameraDefault(&c);
+    if (focal_pt_dist > 0.0f) setFocalDist(&c, focal_pt_dist);
+    vec3 p = { position[0], position[1], position[2] }, l = { look_point[0], look_point[1], look_point[2] }, u = { up[0], up[1], up[2] };
+    cameraLookAt(&c, p, l, u);
+    cam_to_abi(out, c);
+    Camera_destroy(&c);
+}
+REF_API void ref_film_dimension(crt_film* out, float fov, int w, int h, const crt_camera* cam)
+{
+    Camera c; cam_from_abi(&c, cam);
+    Film f; memset(&f, 0, sizeof f);
+    f.fov = fov; f.frame_res_width = w; f.frame_res_height = h;
+    calcFilmDimension(&f, &c);
+    out->fov = f.fov; out->frame_length = f.frame_length; out->frame_height = f.frame_height; out->pixel_length = f.pixel_length;
+    out->frame_res_width = w; out->frame_res_height = h;
+}
+REF_API void ref_primary_rays(const crt_camera* cam, const crt_film* film, unsigned first_pixel, size_t n,
+                              const float* image_samples, const float* lens_samples, crt_ray* rays)
+{
+    Camera c; cam_from_abi(&c, cam);
+    Film f; memset(&f, 0, sizeof f);
+    f.fov = film->fov; f.frame_length = film->frame_length; f.frame_height = film->frame_height; f.pixel_length = film->pixel_length;
+    f.frame_res_width = film->frame_res_width; f.frame_res_height = film->frame_res_height;
+    for (size_t i = 0; i < n; i++) {
+        vec2 is = { image_samples ? image_samples[2*i] : 0.5f, image_samples ? image_samples[2*i+1] : 0.5f };
+        vec2 ls = { lens_samples ? lens_samples[2*i] : 0.5f, lens_samples ? lens_samples[2*i+1] : 0.5f };
+        vec2 ic;
+        calcImageCoord(ic, &f, is, (int)(first_pixel + i));          /* main.cpp:108 */
+        Ray ray;
+        calcCameraRay(&ray, ic, &c, ls);                              /* main.cpp:113 */
+        memcpy(rays + i, &ray, sizeof(crt_ray));
+    }
+}
+
 REF_API int ref_sizes(int* shaderec, int* node4, int* node2, int* object_t)
 {
     *shaderec = (int)sizeof(ShadeRec); *node4 = (int)sizeof(BVHNode4); *node2 = (int)sizeof(BVHNode); *object_t = (int)sizeof(Object_t);

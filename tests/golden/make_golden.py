@@ -52,8 +52,27 @@ def golden_rays(name):
     return np.ascontiguousarray(rays), ld
 
 
+def camera_golden():
+    """Primary rays by the reference's own camera.cpp: the last 4096 pixels with seeded samples and
+    the first 4096 with the (0.5, 0.5) default."""
+    import camera_cases as cc
+    for name, (pos, look, up, fpd, lens, fov, w, h) in cc.CASES.items():
+        cam = ol.ref_camera(pos, look, up, fpd, lens)
+        flm = ol.film("ref", cam, fov, w, h)
+        m = 4096
+        first = w * h - m
+        isamp, lsamp = cc.samples(name, m)
+        np.savez_compressed(os.path.join(HERE, "camera_" + name + ".npz"),
+                            camera=np.frombuffer(ol.struct_bytes(cam), np.uint8), film=np.frombuffer(ol.struct_bytes(flm), np.uint8),
+                            first_pixel=np.array([first], np.int64), image_samples=isamp, lens_samples=lsamp,
+                            rays=ol.primary_rays("ref", cam, flm, first, m, isamp, lsamp),
+                            rays_center=ol.primary_rays("ref", cam, flm, 0, m))
+        print("camera_" + name, "ok")
+
+
 def main():
     assert ol.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    camera_golden()
     for name, (make, _) in SCENES.items():
         si = make()
         rays, ld = golden_rays(name)

@@ -41,6 +41,17 @@ def oracle():
         L.oracle_shadow_object.restype = C.c_float
         L.oracle_ray_aabb.argtypes = [vp, vp, vp]
         L.oracle_ray_aabb.restype = C.c_float
+        f3 = C.POINTER(C.c_float)
+        L.oracle_camera_init.argtypes = [C.POINTER(api.CrtCamera), C.c_int, C.c_float, C.c_float]
+        L.oracle_camera_init.restype = None
+        L.oracle_camera_look_at.argtypes = [C.POINTER(api.CrtCamera), f3, f3, f3]
+        L.oracle_camera_look_at.restype = None
+        L.oracle_camera_set_focal_dist.argtypes = [C.POINTER(api.CrtCamera), C.c_float]
+        L.oracle_camera_set_focal_dist.restype = None
+        L.oracle_film_dimension.argtypes = [C.POINTER(api.CrtFilm), C.c_float, C.c_int, C.c_int, C.POINTER(api.CrtCamera)]
+        L.oracle_film_dimension.restype = None
+        L.oracle_primary_rays.argtypes = [C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm), C.c_uint, C.c_size_t, vp, vp, vp]
+        L.oracle_primary_rays.restype = None
         _oracle = L
     return _oracle
 
@@ -70,6 +81,13 @@ def ref():
         L.ref_ray_aabb4.argtypes = [vp, vp, vp, vp]
         L.ref_ray_aabb4.restype = None
         L.ref_sizes.argtypes = [C.POINTER(C.c_int)] * 4
+        f3 = C.POINTER(C.c_float)
+        L.ref_camera_setup.argtypes = [C.POINTER(api.CrtCamera), C.c_int, C.c_float, C.c_float, C.c_float, f3, f3, f3]
+        L.ref_camera_setup.restype = None
+        L.ref_film_dimension.argtypes = [C.POINTER(api.CrtFilm), C.c_float, C.c_int, C.c_int, C.POINTER(api.CrtCamera)]
+        L.ref_film_dimension.restype = None
+        L.ref_primary_rays.argtypes = [C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm), C.c_uint, C.c_size_t, vp, vp, vp]
+        L.ref_primary_rays.restype = None
         _ref = L
     return _ref
 
@@ -214,3 +232,46 @@ def same_bits(a, b):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+# ---- primary rays ---------------------------------------------------------------------------
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def struct_bytes(st):
+    return bytes(memoryview(st))
+
+
+def oracle_camera(position, look, up=(0.0, 1.0, 0.0), focal_pt_dist=None, thin_lens=None):
+    """init -> optional setFocalDist -> lookAt, by the oracle's restatement."""
+    L = oracle()
+    cam = api.CrtCamera()
+    L.oracle_camera_init(C.byref(cam), 1 if thin_lens else 0, *(thin_lens or (0.0, 0.0)))
+    if focal_pt_dist is not None:
+        L.oracle_camera_set_focal_dist(C.byref(cam), float(focal_pt_dist))
+    L.oracle_camera_look_at(C.byref(cam), _f3(position), _f3(look), _f3(up))
+    return cam
+
+
+def ref_camera(position, look, up=(0.0, 1.0, 0.0), focal_pt_dist=None, thin_lens=None):
+    """The same sequence by the reference's own camera.cpp."""
+    cam = api.CrtCamera()
+    fl, lr = thin_lens or (0.0, 0.0)
+    ref().ref_camera_setup(C.byref(cam), 1 if thin_lens else 0, fl, lr, float(focal_pt_dist or -1.0), _f3(position), _f3(look), _f3(up))
+    return cam
+
+
+def film(which, cam, fov, w, h):
+    f = api.CrtFilm()
+    (oracle().oracle_film_dimension if which == "oracle" else ref().ref_film_dimension)(C.byref(f), float(fov), int(w), int(h), C.byref(cam))
+    return f
+
+
+def primary_rays(which, cam, flm, first_pixel, n, image_samples=None, lens_samples=None):
+    rays = np.empty((n, 6), np.float32)
+    fn = oracle().oracle_primary_rays if which == "oracle" else ref().ref_primary_rays
+    a = None if image_samples is None else np.ascontiguousarray(image_samples, np.float32)
+    b = None if lens_samples is None else np.ascontiguousarray(lens_samples, np.float32)
+    fn(C.byref(cam), C.byref(flm), int(first_pixel), int(n), None if a is None else _p(a), None if b is None else _p(b), _p(rays))
+    return rays
