@@ -342,7 +342,19 @@ bool tri_overlaps_cell(const float* t0, const float* t1, const float* t2, const 
     return fabsf(s) <= r;
 }
 
-void build_grid(Builder& B)
+/* (int)clamp(v, 0, n - 1) of uniformgrid.h:100-105, with a NaN coordinate (which the reference would
+ * convert to int, undefined) sent to cell 0 so that no index can leave the grid */
+static inline int cell_of(float v, int n)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= (float)n - 1) return n - 1;
+    return (int)v;
+}
+
+/* Returns CRT_E_INVALID when the reference's resolution formula has no usable value: a zero-volume
+ * or non-finite bounding box makes s zero / NaN and the reference then converts inf or NaN to int
+ * (uniformgrid.h:73-80, undefined behaviour there); CRT_E_TOOBIG beyond 2^30 cells. */
+int build_grid(Builder& B)
 {
     const int multiplier = 3;                           /* buildscene.h:705 */
     crt_grid& g = B.grid;
@@ -356,9 +368,13 @@ void build_grid(Builder& B)
     for (int i = 0; i < 3; i++) { g.bmin[i] = r.mn[i]; g.bmax[i] = r.mx[i]; }
     g.wx = r.mx[0] - r.mn[0]; g.wy = r.mx[1] - r.mn[1]; g.wz = r.mx[2] - r.mn[2];
     float s = powf(g.wx * g.wy * g.wz / B.n, 0.33333f);
-    g.nx = (int)(g.wx * multiplier / s + 1);
-    g.ny = (int)(g.wy * multiplier / s + 1);
-    g.nz = (int)(g.wz * multiplier / s + 1);
+    const float fx = g.wx * multiplier / s + 1, fy = g.wy * multiplier / s + 1, fz = g.wz * multiplier / s + 1;
+    const float lim = 1048576.0f;
+    if (!(fx >= 1.0f && fx < lim && fy >= 1.0f && fy < lim && fz >= 1.0f && fz < lim)) return CRT_E_INVALID;
+    g.nx = (int)fx;
+    g.ny = (int)fy;
+    g.nz = (int)fz;
+    if ((long long)g.nx * g.ny * g.nz > (1ll << 30)) return CRT_E_TOOBIG;
     g.num_cells = g.nx * g.ny * g.nz;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float ux = g.wx / nx, uy = g.wy / ny, uz = g.wz / nz;
@@ -373,8 +389,8 @@ void build_grid(Builder& B)
         const float w[3] = { g.wx, g.wy, g.wz };
         const int nn[3] = { nx, ny, nz };
         for (int i = 0; i < 3; i++) {
-            lo[i] = (int)clampf(((a.mn[i] - r.mn[i]) / w[i]) * nn[i], 0.0f, (float)nn[i] - 1);
-            hi[i] = (int)clampf(((a.mx[i] - r.mn[i]) / w[i]) * nn[i], 0.0f, (float)nn[i] - 1);
+            lo[i] = cell_of(((a.mn[i] - r.mn[i]) / w[i]) * nn[i], nn[i]);
+            hi[i] = cell_of(((a.mx[i] - r.mn[i]) / w[i]) * nn[i], nn[i]);
         }
         bool tri = is_tri(B.type[k]);
         const float* v = tri ? B.in->tri_verts + (size_t)B.ref[k] * 9 : 0;
@@ -398,6 +414,7 @@ void build_grid(Builder& B)
     B.cell_items.assign(pairs_obj.size(), 0);
     std::vector<int32_t> fill(B.cell_start.begin(), B.cell_start.end() - 1);
     for (size_t i = 0; i < pairs_obj.size(); i++) B.cell_items[fill[pairs_cell[i]]++] = pairs_obj[i];
+    return CRT_OK;
 }
 
 } // namespace
@@ -465,7 +482,8 @@ int crt_build_scene(const crt_scene_input* in, int accel, crt_built_scene** out)
             B.nodes2.resize((size_t)2 * na - 1);
             build2(B, B.nng, na, 0, 0);
         } else if (accel == CRT_ACCEL_GRID) {
-            build_grid(B);
+            const int rc = build_grid(B);
+            if (rc != CRT_OK) { delete bs; return rc; }
         }
         bs->tri.assign(in->tri_verts, in->tri_verts + (size_t)in->num_tris * 9);
         if (in->num_shapes) bs->shapes.assign(in->shapes, in->shapes + in->num_shapes);
@@ -484,6 +502,9 @@ int crt_build_scene(const crt_scene_input* in, int accel, crt_built_scene** out)
     } catch (const std::bad_alloc&) {
         delete bs;
         return CRT_E_NOMEM;
+    } catch (const std::exception&) {                   /* nothing may cross the C ABI */
+        delete bs;
+        return CRT_E_INVALID;
     }
     *out = bs;
     return CRT_OK;
