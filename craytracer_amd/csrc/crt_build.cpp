@@ -367,6 +367,13 @@ int build_grid(Builder& B)
         }
     for (int i = 0; i < 3; i++) { g.bmin[i] = r.mn[i]; g.bmax[i] = r.mx[i]; }
     g.wx = r.mx[0] - r.mn[0]; g.wy = r.mx[1] - r.mn[1]; g.wz = r.mx[2] - r.mn[2];
+    if (B.n - B.nng == 0) {                             /* nothing to put in a grid: one empty cell inside the
+                                                           inverted box, which no ray enters */
+        g.nx = g.ny = g.nz = 1; g.num_cells = 1;
+        B.cell_start.assign(2, 0);
+        B.cell_items.clear();
+        return CRT_OK;
+    }
     float s = powf(g.wx * g.wy * g.wz / B.n, 0.33333f);
     const float fx = g.wx * multiplier / s + 1, fy = g.wy * multiplier / s + 1, fz = g.wz * multiplier / s + 1;
     const float lim = 1048576.0f;
