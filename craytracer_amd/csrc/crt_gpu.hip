@@ -45,6 +45,8 @@ struct crt_scene {
     DevScene dev;
     bool tri_only;            /* every object is a triangle type */
     bool accel_tri_only;      /* every object below the accelerator is a triangle type */
+    bool accel_bounded;       /* ... or another shape whose box bounds it: sphere, rectangle, disk (shapes.cpp:146-263) */
+    int depth4, depth2;       /* levels of the QBVH / BVH */
     int mode;                 /* requested crt_traverse_mode */
     bool count;
     int num_cus;
@@ -74,7 +76,7 @@ namespace {
 
 int resolved_mode(const crt_scene* s)
 {
-    if (s->mode == CRT_TRAVERSE_AUTO) return s->accel_tri_only ? CRT_TRAVERSE_PRUNED : CRT_TRAVERSE_EXACT;
+    if (s->mode == CRT_TRAVERSE_AUTO) return s->accel_bounded ? CRT_TRAVERSE_PRUNED : CRT_TRAVERSE_EXACT;
     return s->mode;
 }
 
@@ -323,13 +325,19 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     try {
         /* object records (48 B) in final order */
         std::vector<float4> objs((size_t)n * 3);
-        bool all_tri = true, accel_tri = true;
+        bool all_tri = true, accel_tri = true, accel_bounded = true;
         for (int i = 0; i < n; i++) {
             const int t = desc->obj_type[i], r = desc->obj_ref[i];
             const bool tri = (t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE);
             float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             if (tri) memcpy(v, desc->tri_verts + (size_t)r * 9, sizeof v);
-            else { all_tri = false; if (i >= nng) accel_tri = false; }
+            else {
+                all_tri = false;
+                if (i >= nng) {
+                    accel_tri = false;
+                    if (!(t == CRT_SPHERE || t == CRT_RECTANGLE || t == CRT_DISK)) accel_bounded = false;
+                }
+            }
             float idf, tf, rf;
             memcpy(&idf, &desc->obj_id[i], 4); memcpy(&tf, &t, 4); memcpy(&rf, &r, 4);
             objs[(size_t)i*3 + 0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -338,6 +346,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         }
         s->tri_only = all_tri;
         s->accel_tri_only = accel_tri;
+        s->accel_bounded = accel_bounded;
+        s->depth4 = d4; s->depth2 = d2;
         if ((desc->accel == CRT_ACCEL_BVH4 || desc->accel == CRT_ACCEL_BVH) && n - nng > 0) {   /* box of the triangles under the accelerator */
             float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
             bool any = false;
@@ -360,8 +370,9 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             }
         }
         s->binning = true;
-        if (desc->accel == CRT_ACCEL_BVH4 && !accel_tri && d4 > CRT_EXACT4_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
-        if (desc->accel == CRT_ACCEL_BVH && !accel_tri && d2 > CRT_EXACT2_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
+        /* the reference-control-flow kernels keep one frame per tree level */
+        if (desc->accel == CRT_ACCEL_BVH4 && !accel_bounded && d4 > CRT_EXACT4_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
+        if (desc->accel == CRT_ACCEL_BVH && !accel_bounded && d2 > CRT_EXACT2_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
 
         std::vector<float4> n4;
         if (desc->accel == CRT_ACCEL_BVH4) {
@@ -483,6 +494,9 @@ void crt_scene_destroy(crt_scene* s)
 int crt_scene_set_traverse_mode(crt_scene* s, int mode)
 {
     if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;
+    if (mode == CRT_TRAVERSE_EXACT &&
+        ((s->dev.accel == CRT_ACCEL_BVH4 && s->depth4 > CRT_EXACT4_DEPTH) || (s->dev.accel == CRT_ACCEL_BVH && s->depth2 > CRT_EXACT2_DEPTH)))
+        return CRT_E_TOOBIG;                             /* deeper than the frame stack of the EXACT kernels */
     s->mode = mode;
     return CRT_OK;
 }

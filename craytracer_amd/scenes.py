@@ -304,6 +304,26 @@ def buddha_like(n_lat=512, n_lon=1024, seed=3):
 # ---------------------------------------------------------------------------------------
 # ray sets
 
+def lit_mesh_scene(n_lat=512, n_lon=1024, seed=3):
+    """A ~1M-triangle displaced blob in a room with the usual non-mesh furniture of a render scene:
+    an area light (rectangle) under the ceiling, a wall rectangle, two spheres, a disk, and a ground
+    plane (not under the accelerator).  Every shape under the accelerator has a bounding box."""
+    sl = ShapeList()
+    sl.rectangle((0.35, 0.995, 0.35), (0.3, 0.0, 0.0), (0.0, 0.0, 0.3))            # light
+    sl.sphere((0.2, 0.15, 0.8), 0.12)
+    sl.plane((0.0, -0.01, 0.0), (0.0, 1.0, 0.0))
+    sl.rectangle((0.02, 0.1, 0.1), (0.0, 0.5, 0.0), (0.0, 0.0, 0.6))                # panel near a wall
+    sl.disk((0.8, 0.05, 0.2), _normalize32((0.0, 1.0, 0.2)), 0.1)
+    sl.sphere((0.8, 0.8, 0.8), 0.1, 0.3, 2.5, 2.0)                                  # partial sphere
+    base = sl.to_input()
+    blob = blob_mesh(n_lat, n_lon, seed, radius=1.0, displace=0.45) * F32(0.4) + np.tile(np.array([0.5, 0.5, 0.5], F32), 3)
+    tris = np.concatenate([room_tris((0, 0, 0), (1, 1, 1)), blob.astype(F32)], 0)
+    n_t = len(tris)
+    obj_type = np.concatenate([base.obj_type, np.full(n_t, api.SMOOTH_TRIANGLE, np.int32)])
+    obj_ref = np.concatenate([base.obj_ref, np.arange(n_t, dtype=np.int32)])
+    return api.SceneInput(tris, base.shapes, obj_type, obj_ref)
+
+
 def scene_bounds(si):
     v = si.tri_verts.reshape(-1, 3)
     if len(v) == 0:

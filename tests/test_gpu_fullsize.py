@@ -220,3 +220,45 @@ def test_other_accelerators_at_1m_triangles(accel):
     assert ol.same_bits(hits[:m], o.intersect(rays[:m], mode=api.TRAVERSE_EXACT, nthreads=threads))
     wt, wocc = o.shadow(rays[:m], ld[:m], nthreads=threads)
     assert ol.same_bits(st[:m], wt) and np.array_equal(occ[:m], wocc)
+
+
+@pytest.mark.parametrize("accel", [api.ACCEL_BVH4, api.ACCEL_BVH])
+def test_mesh_with_lights_and_spheres_takes_the_pruned_path(accel):
+    """~1M triangles plus rectangles (area light), spheres, a disk and a ground plane: AUTO must
+    resolve to the pruned walk (all boxes bound their shapes) and that walk must equal the
+    reference's control flow bit for bit -- on 2^20 incoherent rays GPU vs GPU, and against the
+    oracle in the reference's control flow on a sample."""
+    import torch
+    si = scenes.lit_mesh_scene()
+    built = api.BuiltScene(si, accel)
+    sc = api.Scene(built, 0)
+    assert sc.traverse_mode() == api.TRAVERSE_PRUNED
+    n = 1 << 20
+    lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
+    prim = scenes.random_rays(n, lo, hi, seed=23)
+    h0 = sc.intersect(prim)
+    ok = h0["obj"] >= 0
+    p = prim[:, :3] + prim[:, 3:] * np.where(ok, h0["t"], 0)[:, None]
+    d = np.random.default_rng(5).normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([p, d], 1).astype(np.float32)              # origins ON surfaces, random directions
+    pruned = sc.intersect(rays)
+    ld = np.full(n, 0.6, np.float32)
+    st_p, occ_p = sc.shadow(rays, ld)
+    if accel == api.ACCEL_BVH4 or True:
+        sc.set_traverse_mode(api.TRAVERSE_EXACT)
+        exact = sc.intersect(rays)
+        sc.set_traverse_mode(api.TRAVERSE_AUTO)
+        bad = pruned.view(np.uint8).reshape(n, -1) != exact.view(np.uint8).reshape(n, -1)
+        assert not bad.any(), (int(bad.any(1).sum()), pruned[bad.any(1)][:4], exact[bad.any(1)][:4])
+    types = si.obj_type[pruned["obj"][pruned["obj"] >= 0]]
+    assert (types == api.RECTANGLE).sum() > 1000 and (types == api.SPHERE).sum() > 1000    # the shapes do get hit
+    m = 1 << 14
+    o = ol.OracleScene(si, accel, built=built)
+    want = o.intersect(rays[:m], mode=api.TRAVERSE_EXACT, nthreads=min(os.cpu_count() or 1, 16))
+    same_id = (pruned["obj"][:m] == want["obj"]) & (pruned["part"][:m] == want["part"])
+    dt = np.abs(pruned["t"][:m].astype(np.float64) - want["t"]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"]))
+    assert (~(same_id & (dt | (pruned["t"][:m] == want["t"])))).sum() <= 4        # sphere seams (class T4)
+    wt, wocc = o.shadow(rays[:m], ld[:m], nthreads=min(os.cpu_count() or 1, 16))
+    assert (st_p[:m] != wt).sum() <= 4 and (occ_p[:m] != wocc).sum() <= 4
+    sc.close()
