@@ -149,7 +149,7 @@ int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
             else if (n.type[c] < 0 || n.type[c] > 4 || n.child[c] < 0 || n.child[c] + n.type[c] > d->num_obj) return CRT_E_INVALID;
         }
         *d4 = depth4(d);
-        if (3 * *d4 + 1 > CRT_STACK_MAX) return CRT_E_TOOBIG;       /* per-lane stack: <= 3 pending siblings per level */
+        if (CRT_STACK_PER_LEVEL_PRUNED * *d4 + 1 > CRT_STACK_MAX) return CRT_E_TOOBIG;   /* per-lane stack: <= 3 pending siblings per level */
     }
     if (d->accel == CRT_ACCEL_BVH && na > 0) {
         if (!d->nodes2 || d->num_nodes2 < 1) return CRT_E_INVALID;
@@ -254,10 +254,10 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest_exact<TRI_ONLY, COUNT>, la, st)
-                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT>, la, st, true);
-    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, false>, la, st)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false>, la, st, true);
+    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true)
+                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true);
+    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st);
     default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st);
     }
@@ -268,8 +268,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
-    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2_exact<TRI_ONLY, COUNT, true>, la, st)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true>, la, st, true);
+    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
     default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
     }
@@ -370,9 +370,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             }
         }
         s->binning = true;
-        /* the reference-control-flow kernels keep one frame per tree level */
-        if (desc->accel == CRT_ACCEL_BVH4 && !accel_bounded && d4 > CRT_EXACT4_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
-        if (desc->accel == CRT_ACCEL_BVH && !accel_bounded && d2 > CRT_EXACT2_DEPTH) { free_scene(s); return CRT_E_TOOBIG; }
+        /* the reference-control-flow QBVH walk adds one frame marker per tree level to the stack */
+        if (desc->accel == CRT_ACCEL_BVH4 && !accel_bounded && CRT_STACK_PER_LEVEL_EXACT * d4 + 1 > CRT_STACK_MAX) { free_scene(s); return CRT_E_TOOBIG; }
 
         std::vector<float4> n4;
         if (desc->accel == CRT_ACCEL_BVH4) {
@@ -494,9 +493,8 @@ void crt_scene_destroy(crt_scene* s)
 int crt_scene_set_traverse_mode(crt_scene* s, int mode)
 {
     if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;
-    if (mode == CRT_TRAVERSE_EXACT &&
-        ((s->dev.accel == CRT_ACCEL_BVH4 && s->depth4 > CRT_EXACT4_DEPTH) || (s->dev.accel == CRT_ACCEL_BVH && s->depth2 > CRT_EXACT2_DEPTH)))
-        return CRT_E_TOOBIG;                             /* deeper than the frame stack of the EXACT kernels */
+    if (mode == CRT_TRAVERSE_EXACT && s->dev.accel == CRT_ACCEL_BVH4 && CRT_STACK_PER_LEVEL_EXACT * s->depth4 + 1 > CRT_STACK_MAX)
+        return CRT_E_TOOBIG;                             /* one frame marker per level on top of the pending siblings */
     s->mode = mode;
     return CRT_OK;
 }

@@ -16,10 +16,13 @@
 #ifndef CRT_LDS_DEPTH
 #define CRT_LDS_DEPTH  16
 #endif
-#define CRT_OVF_DEPTH  32
+#define CRT_OVF_DEPTH  48
 #define CRT_STACK_MAX  (CRT_LDS_DEPTH + CRT_OVF_DEPTH)
-#define CRT_EXACT4_DEPTH 16     /* QBVH levels the EXACT kernel's frame stack holds */
-#define CRT_EXACT2_DEPTH 64     /* binary-BVH levels the EXACT kernel's frame stack holds */
+/* stack entries a QBVH walk can need per tree level: 3 pending siblings, + 1 frame marker in the
+ * reference-control-flow (EXACT) walk */
+#define CRT_STACK_PER_LEVEL_PRUNED 3
+#define CRT_STACK_PER_LEVEL_EXACT  4
+#define CRT_FRAME_MARK 0xFFFFFFFFu   /* not a leaf word: count field 7 */
 
 struct LaunchArgs {
     const crt_ray* rays;
@@ -274,7 +277,16 @@ CRT_DEV unsigned refill(unsigned* queue_head, unsigned n, unsigned long long idl
  * the test is applied when a child is pushed and again when it is popped, which is the same
  * as applying it when the recursive version reaches the child.
  * ===================================================================================== */
-template <bool TRI_ONLY, bool COUNT>
+/* EXACT = the reference's own control flow on the same stack machine.  In BVH4IntersectTest the
+ * threshold a child is tested against is min_t LOCAL to the node visit (bvh4.h:354-371): the
+ * smallest t returned by the children visited before it.  A subtree's return value is the smallest t
+ * of all primitives tested inside it, so "local min_t of node V" = smallest t found since V was
+ * entered.  The walk keeps that number for the innermost open node in cur_min; entering an inner
+ * node pushes a frame marker holding the parent's value and restarts cur_min at TMAX, and popping
+ * the marker (all of the node's children done) folds the node's result into the parent's:
+ * `if (t < min_t) min_t = t` (bvh4.h:366-370).  The hit record that survives this chain of strict
+ * comparisons is the first-found global minimum, which best_t / best track as in the pruned walk. */
+template <bool TRI_ONLY, bool COUNT, bool EXACT = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
     bool clean = true;            /* no product of the slab test can be NaN for this ray */
     bool wave_clean = true;       /* wave-uniform: every ray loaded so far into this wave was clean */
     float best_t = CRT_TMAX;
+    float cur_min = CRT_TMAX;     /* EXACT: min_t of the innermost open node visit */
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
     for (;;) {
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
             if (idx != 0xFFFFFFFFu) {
                 ri = la.perm ? la.perm[idx] : idx;
                 ray = load_ray(la.rays, ri);
+                cur_min = CRT_TMAX;
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
                 const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
                 onx = sx ? 0u : 48u;  ofx = 48u - onx;
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
                     const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
                     if (COUNT) c_nodes++;
+                    if (EXACT) { st.push(CRT_FRAME_MARK, cur_min); cur_min = CRT_TMAX; }      /* a new node visit opens: bvh4.h:354 */
                     float k0, k1, k2, k3;
                     if (wave_clean) {
                         box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
@@ -366,10 +381,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
                     const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
                     const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
-                    if (s3k < best_t) st.push(s3w, s3k);
-                    if (s2k < best_t) st.push(s2w, s2k);
-                    if (s1k < best_t) st.push(s1w, s1k);
-                    if (s0k < best_t) { cur = s0w; need_pop = false; }
+                    const float thr = EXACT ? cur_min : best_t;                       /* EXACT: TMAX here, the visit has just opened */
+                    if (s3k < thr) st.push(s3w, s3k);
+                    if (s2k < thr) st.push(s2w, s2k);
+                    if (s1k < thr) st.push(s1w, s1k);
+                    if (s0k < thr) { cur = s0w; need_pop = false; }
                 } else {
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
@@ -381,6 +397,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                         const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
                         if (COUNT) c_prims++;
                         if (t < best_t) { best_t = t; best = h; }
+                        if (EXACT && t < cur_min) cur_min = t;                         /* bvh4.h:378-382, the open node's min_t */
                     }
                     if (count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
 #else
@@ -389,6 +406,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                         const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
                         if (COUNT) c_prims++;
                         if (t < best_t) { best_t = t; best = h; }
+                        if (EXACT && t < cur_min) cur_min = t;
                     }
 #endif
                 }
@@ -397,7 +415,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     while (st.sp > 0) {
                         unsigned w; float key;
                         st.pop(&w, &key);
-                        if (key < best_t) { cur = w; walking = true; break; }
+                        if (EXACT && w == CRT_FRAME_MARK) {                            /* the node visit closes: bvh4.h:366-370 */
+                            cur_min = cur_min < key ? cur_min : key;
+                            continue;
+                        }
+                        if (key < (EXACT ? cur_min : best_t)) { cur = w; walking = true; break; }
                     }
                 }
             }
@@ -593,7 +615,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
  *   q0 = lmin.xyz lmax.x   q1 = lmax.yz rmin.xy   q2 = rmin.z rmax.xyz   q3 = left word, right word
  *   word = inner-record index, or CRT_LEAF_BIT | object index (final order).
  * Lanes are refilled from the queue as in k_bvh4_closest. */
-template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+/* EXACT = BVHIntersectTest / BVHShadowIntersectTest as written (intersect.h:310-362): every
+ * box-overlapped subtree is walked, nothing is culled by t; `t1 < t2 ? left : right` at every level
+ * makes the LAST of equal hits in left-first order win, which is the `<=` below. */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
@@ -656,8 +681,8 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                     const float rbt = dev_ray_aabb_inv(rmn, rmx, ray, ia, ib, ic, &rt0);
                     const float lkey = lt0 > CRT_K_EPSILON ? lt0 : ninf;
                     const float rkey = rt0 > CRT_K_EPSILON ? rt0 : ninf;
-                    const bool lv = lbt < CRT_TMAX && !(lkey > best_t);
-                    const bool rv = rbt < CRT_TMAX && !(rkey > best_t);
+                    const bool lv = lbt < CRT_TMAX && (EXACT || !(lkey > best_t));
+                    const bool rv = rbt < CRT_TMAX && (EXACT || !(rkey > best_t));
                     const unsigned lw = __float_as_uint(q3.x), rw = __float_as_uint(q3.y);
                     if (lv) {
                         if (rv) st.push(rw, rkey);
@@ -669,7 +694,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                     while (st.sp > 0) {
                         unsigned w; float key;
                         st.pop(&w, &key);
-                        if (!(key > best_t)) { cur = w; walking = true; break; }
+                        if (EXACT || !(key > best_t)) { cur = w; walking = true; break; }
                     }
                 }
             }
@@ -800,178 +825,6 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
                 store_hit(la.hits, ri, t, best);
             } else {
                 if (!done) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, bound, CRT_TMAX, &c_prims);  /* :298-307 */
-                if (la.t_out) la.t_out[ri] = t;
-                if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
-            }
-            if (COUNT) c_rays++;
-        }
-    }
-    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
-}
-
-/* =====================================================================================
- * EXACT mode: the reference's own control flow, for scenes whose boxes do not bound their
- * objects (rotated / scaled instances).  Recursion is unrolled onto a per-lane frame stack in
- * private memory; these kernels serve small analytic scenes, not the throughput path.
- * ===================================================================================== */
-struct Frame4 { unsigned node; int k; float local_t; DHit hit; };
-
-/* BVH4IntersectTest with min_t local to each node visit (bvh4.h:354-388) */
-template <bool TRI_ONLY, bool COUNT>
-__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest_exact(DevScene sc, LaunchArgs la)
-{
-    const unsigned lane = threadIdx.x & 63;
-    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
-    for (;;) {
-        const unsigned base = next_batch(la.queue_head);
-        if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
-            const DRay ray = load_ray(la.rays, ri);
-            const float ia = 1.0f / ray.dx, ib = 1.0f / ray.dy, ic = 1.0f / ray.dz;
-            const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
-            const bool px = ray.dx > 0.0f;
-            Frame4 fr[CRT_EXACT4_DEPTH];
-            int depth = -1;
-            float ret_t = CRT_TMAX;
-            DHit ret_h; ret_h.obj = -1; ret_h.part = -1; ret_h.beta = 0.0f; ret_h.gamma = 0.0f;
-            bool returning = false;
-            if (sc.n_accel > 0) { depth = 0; fr[0].node = 0; fr[0].k = 0; fr[0].local_t = CRT_TMAX; fr[0].hit = ret_h; }
-            while (depth >= 0) {
-                Frame4 f = fr[depth];
-                if (returning) {                                                       /* bvh4.h:366-370 */
-                    if (ret_t < f.local_t) { f.local_t = ret_t; f.hit = ret_h; }
-                    returning = false;
-                } else if (COUNT && f.k == 0) c_nodes++;
-                const float4* nd = sc.nodes4 + (size_t)f.node * 8;
-                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
-                float bt[4]; bool lt[4]; unsigned cw[4];
-                bt[0] = box4(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, ray, ia, ib, ic, sx, sy, sz, &lt[0]);
-                bt[1] = box4(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, ray, ia, ib, ic, sx, sy, sz, &lt[1]);
-                bt[2] = box4(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, ray, ia, ib, ic, sx, sy, sz, &lt[2]);
-                bt[3] = box4(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, ray, ia, ib, ic, sx, sy, sz, &lt[3]);
-                cw[0] = __float_as_uint(q6.x); cw[1] = __float_as_uint(q6.y); cw[2] = __float_as_uint(q6.z); cw[3] = __float_as_uint(q6.w);
-                const int ax2 = __float_as_int(q7.x);
-                const float dax = ax2 == 0 ? ray.dx : (ax2 == 1 ? ray.dy : ray.dz);
-                const bool p2 = dax > 0.0f;
-                int order[4];
-                if (px) { order[0] = 0; order[1] = 1; order[2] = p2 ? 2 : 3; order[3] = p2 ? 3 : 2; }
-                else    { order[0] = p2 ? 2 : 3; order[1] = p2 ? 3 : 2; order[2] = 1; order[3] = 0; }
-                bool descended = false;
-                while (f.k < 4) {
-                    const int idx = order[f.k];
-                    f.k++;
-                    if (bt[idx] < f.local_t || (lt[idx] && bt[idx] < CRT_TMAX)) {      /* bvh4.h:358 */
-                        const unsigned w = cw[idx];
-                        if (!(w & CRT_LEAF_BIT)) {
-                            if (depth + 1 < CRT_EXACT4_DEPTH) {
-                                fr[depth] = f;
-                                depth++;
-                                fr[depth].node = w & CRT_NODE_MASK; fr[depth].k = 0; fr[depth].local_t = CRT_TMAX; fr[depth].hit = ret_h;
-                                descended = true;
-                                break;
-                            }
-                        } else {
-                            const int count = (int)((w >> 28) & 7u), first = (int)(w & 0x0FFFFFFFu);
-                            for (int j = 0; j < count; j++) {
-                                DHit h;
-                                const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
-                                if (COUNT) c_prims++;
-                                if (t < f.local_t) { f.local_t = t; f.hit = h; }
-                            }
-                        }
-                    }
-                }
-                if (!descended) { ret_t = f.local_t; ret_h = f.hit; returning = true; depth--; }
-            }
-            float best_t = ret_t;
-            DHit best = ret_h;
-            linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-            store_hit(la.hits, ri, best_t, best);
-            if (COUNT) c_rays++;
-        }
-    }
-    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, false);
-}
-
-struct Frame2 { int node; int state; float t1; DHit h1; };
-
-/* BVHIntersectTest / BVHShadowIntersectTest as written (intersect.h:310-362): every
- * box-overlapped subtree is walked, the pick is `t1 < t2 ? left : right`. */
-template <bool TRI_ONLY, bool COUNT, bool SHADOW>
-__global__ __launch_bounds__(CRT_BLOCK) void k_bvh2_exact(DevScene sc, LaunchArgs la)
-{
-    const unsigned lane = threadIdx.x & 63;
-    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
-    for (;;) {
-        const unsigned base = next_batch(la.queue_head);
-        if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
-            const DRay ray = load_ray(la.rays, ri);
-            Frame2 fr[CRT_EXACT2_DEPTH];
-            int depth = -1;
-            float ret_t = CRT_TMAX;
-            DHit none; none.obj = -1; none.part = -1; none.beta = 0.0f; none.gamma = 0.0f;
-            DHit ret_h = none;
-            if (sc.n_accel > 0) {
-                const float4 a = sc.nodes2[0], b = sc.nodes2[1];
-                float bmin[3] = { a.x, a.y, a.z }, bmax[3] = { b.x, b.y, b.z }, t0;
-                if (COUNT) c_nodes++;
-                if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX) { depth = 0; fr[0].node = 0; fr[0].state = 0; fr[0].t1 = CRT_TMAX; fr[0].h1 = none; }
-            }
-            while (depth >= 0) {
-                Frame2 f = fr[depth];
-                const float4 a = sc.nodes2[(size_t)f.node * 2], b = sc.nodes2[(size_t)f.node * 2 + 1];
-                const int left = __float_as_int(a.w), right = __float_as_int(b.w);
-                if (left < 0) {
-                    DHit h;
-                    ret_t = dev_object<TRI_ONLY>(sc, right, ray, SHADOW, &h);
-                    ret_h = h;
-                    if (COUNT) c_prims++;
-                    depth--;
-                    continue;
-                }
-                if (f.state == 0) {                              /* left child */
-                    const float4 c0 = sc.nodes2[(size_t)left * 2], c1 = sc.nodes2[(size_t)left * 2 + 1];
-                    float bmin[3] = { c0.x, c0.y, c0.z }, bmax[3] = { c1.x, c1.y, c1.z }, t0;
-                    if (COUNT) c_nodes++;
-                    f.state = 1;
-                    if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX && depth + 1 < CRT_EXACT2_DEPTH) {
-                        fr[depth] = f;
-                        depth++;
-                        fr[depth].node = left; fr[depth].state = 0; fr[depth].t1 = CRT_TMAX; fr[depth].h1 = none;
-                        continue;
-                    }
-                    ret_t = CRT_TMAX; ret_h = none;              /* t1 stays TMAX */
-                }
-                if (f.state == 1) {                              /* back from (or skipped) left: record t1, go right */
-                    f.t1 = ret_t; f.h1 = ret_h;
-                    const float4 c0 = sc.nodes2[(size_t)right * 2], c1 = sc.nodes2[(size_t)right * 2 + 1];
-                    float bmin[3] = { c0.x, c0.y, c0.z }, bmax[3] = { c1.x, c1.y, c1.z }, t0;
-                    if (COUNT) c_nodes++;
-                    f.state = 2;
-                    if (dev_ray_aabb(bmin, bmax, ray, &t0) < CRT_TMAX && depth + 1 < CRT_EXACT2_DEPTH) {
-                        fr[depth] = f;
-                        depth++;
-                        fr[depth].node = right; fr[depth].state = 0; fr[depth].t1 = CRT_TMAX; fr[depth].h1 = none;
-                        continue;
-                    }
-                    ret_t = CRT_TMAX; ret_h = none;              /* t2 stays TMAX */
-                }
-                /* state 2: ret_* is t2 */
-                if (f.t1 < ret_t) { ret_t = f.t1; ret_h = f.h1; }                      /* intersect.h:327-338,:360 */
-                depth--;
-            }
-            if (!SHADOW) {
-                float best_t = ret_t;
-                DHit best = ret_h;
-                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-                store_hit(la.hits, ri, best_t, best);
-            } else {
-                const float ld = la.light_dist[ri];
-                float t = ret_t;
-                if (t >= ld) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, t, &c_prims);
                 if (la.t_out) la.t_out[ri] = t;
                 if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
             }

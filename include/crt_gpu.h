@@ -62,8 +62,8 @@ enum crt_accel { CRT_ACCEL_NONE = 0, CRT_ACCEL_GRID = 1, CRT_ACCEL_BVH = 2, CRT_
  *      instances, shapes.cpp:284-304).
  *  CRT_TRAVERSE_AUTO   : PRUNED when every object below the accelerator is a triangle, sphere,
  *      rectangle or disk -- shapes whose reference boxes bound them (shapes.cpp:146-263) -- else EXACT
- *      (instanced / compound / generic shapes).  EXACT keeps one frame per tree level: trees deeper
- *      than 16 QBVH / 64 BVH levels cannot use it (CRT_E_TOOBIG). */
+ *      (instanced / compound / generic shapes).  Stack limits: QBVH depth <= 21 (PRUNED), <= 15
+ *      (EXACT, one frame marker per level); BVH depth <= 63; deeper trees get CRT_E_TOOBIG. */
 enum crt_traverse_mode { CRT_TRAVERSE_AUTO = 0, CRT_TRAVERSE_PRUNED = 1, CRT_TRAVERSE_EXACT = 2 };
 
 /* ---- ray and hit records ---------------------------------------------- */

@@ -151,20 +151,30 @@ def test_tiny_scenes():
             assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
 
 
-def test_counters_match_oracle_pruned_traversal():
-    si = scenes.courtyard(4, 16, 32, seed=2)
-    rays, ld = rayset(si, 4096, 9)
+@pytest.mark.parametrize("mode", [api.TRAVERSE_PRUNED, api.TRAVERSE_EXACT])
+@pytest.mark.parametrize("scene", ["blobs", "analytic"])
+def test_counters_match_the_oracles_walk(scene, mode):
+    """Same boxes tested and same primitives tested as the oracle's walk in that mode: the GPU walk
+    is the same walk, not merely one with the same answers."""
+    si = scenes.courtyard(4, 16, 32, seed=2) if scene == "blobs" else scenes.analytic_scene()
+    if scene == "blobs":
+        rays, ld = rayset(si, 4096, 9)
+    else:
+        rays = scenes.random_rays(4096, np.array([-7, -2, -7], np.float32), np.array([7, 5, 7], np.float32), 31)
     built = api.BuiltScene(si, api.ACCEL_BVH4)
     sc = api.Scene(built, 0)
+    sc.set_traverse_mode(mode)
     sc.enable_counters(True)
     sc.reset_counters()
     sc.intersect(rays)
     c = sc.counters()
     o = ol.OracleScene(si, api.ACCEL_BVH4)
-    _, oc = o.intersect(rays, mode=api.TRAVERSE_PRUNED, counters=True)
+    _, oc = o.intersect(rays, mode=mode, counters=True)
     assert c["rays_closest"] == len(rays)
-    assert c["nodes_visited"] == oc["nodes_visited"]
-    assert c["prims_tested"] == oc["prims_tested"]
+    if scene == "blobs":
+        assert c["nodes_visited"] == oc["nodes_visited"] and c["prims_tested"] == oc["prims_tested"]
+    else:       # a libm seam ray (class T4) may change the walk of that ray
+        assert abs(c["nodes_visited"] - oc["nodes_visited"]) <= 64 and abs(c["prims_tested"] - oc["prims_tested"]) <= 64
     sc.close()
 
 
