@@ -244,7 +244,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), %s, %d %s per GPU per step"
-                               % (args.workload, n_tris, args.accel.upper(), n, "shadow rays from the incoherent hit points toward a ceiling light"
+                               % (args.workload, n_tris, {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel], n, "shadow rays from the incoherent hit points toward a ceiling light"
                                   if shadow else "incoherent bounce-1..3 rays"),
                    "triangles": n_tris, "rays_per_gpu": n, "accel": args.accel.upper(), "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
                    if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),

@@ -10,4 +10,4 @@ for p in "${PASSES[@]}"; do
   i=$((i+1))
   timeout -s KILL 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; exit 1; }
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | grep -A12 "closest<true, false>"
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | grep -A12 "void k_bvh4"
