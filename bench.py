@@ -278,6 +278,22 @@ def main():
         except Exception:
             pass
 
+    if not shadow and args.accel == "bvh4":
+        # secondary metric (BASELINE.json: "any-hit Mrays/s"), outside the timed region: shadow rays from
+        # this batch's hit points toward a ceiling light, same scene, three launches
+        s_rays, s_ld = gen_shadow_rays(sc, si, d_rays, 0xBEEF + rank, device)
+        s_t = torch.empty(n, dtype=torch.float32, device=device)
+        s_occ = torch.empty(n, dtype=torch.uint8, device=device)
+        s_ms = []
+        for _ in range(4):
+            sc.shadow_dev(s_rays.data_ptr(), s_ld.data_ptr(), n, s_t.data_ptr(), s_occ.data_ptr(), stream)
+            s_ms.append(sc.last_kernel_ms() + sc.last_binning_ms())
+        s_best = shard.max_over_ranks(float(np.mean(s_ms[1:])), device)
+        out["any_hit"] = {"metric": "Mrays/s any-hit (shadow rays toward an area light), QBVH",
+                          "value": round(n * world / s_best / 1e3, 1), "unit": "Mrays/s", "ms_per_launch": round(s_best, 4),
+                          "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
+        del s_rays, s_ld, s_t, s_occ
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU checker timed as "the reference's path on the host cores": same tree, same rays
         sys.path.insert(0, os.path.join(ROOT, "tests"))
