@@ -516,7 +516,7 @@ int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_h
 {
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
-    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;                        /* 32-bit queue head */
+    if (n > 0xF0000000u) return CRT_E_TOOBIG;                        /* 32-bit queue head; waves claim 64 slots at a time past the end */
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     LaunchArgs la;
@@ -532,7 +532,7 @@ int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_lig
 {
     if (!s || (n > 0 && (!d_rays || !d_light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
-    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
+    if (n > 0xF0000000u) return CRT_E_TOOBIG;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     LaunchArgs la;
@@ -598,7 +598,7 @@ int crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hi
 {
     if (!s || (n > 0 && (!rays || !hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
-    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
+    if (n > 0xF0000000u) return CRT_E_TOOBIG;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     std::lock_guard<std::mutex> lock(g_chunk_mu);
@@ -624,7 +624,7 @@ int crt_shadow_batch(crt_scene* s, const crt_ray* rays, const float* light_dist,
 {
     if (!s || (n > 0 && (!rays || !light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
-    if (n > 0xFFFFFF00u) return CRT_E_TOOBIG;
+    if (n > 0xF0000000u) return CRT_E_TOOBIG;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     std::lock_guard<std::mutex> lock(g_chunk_mu);
@@ -690,7 +690,7 @@ int crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* film
 {
     if (!cam || !film || (n > 0 && !d_rays) || film->frame_res_width < 1 || cam->type < 0 || cam->type > 1) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
-    if (n > 0xFFFFFF00u || (unsigned long long)first_pixel + n > 0xFFFFFFFFull) return CRT_E_TOOBIG;
+    if (n > 0xF0000000u || (unsigned long long)first_pixel + n > 0xFFFFFFFFull) return CRT_E_TOOBIG;
     DeviceGuard guard(device);
     if (!guard.ok) return CRT_E_HIP;
     hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cam, *film,

@@ -245,7 +245,10 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
  * CRT_REFILL_MIN lanes are idle, one agent-scope atomic claims that many rays for the wave, and
  * each idle lane takes the claimed slot given by its rank among the idle lanes (ballot + mbcnt). */
 #ifndef CRT_REFILL_MIN
-#define CRT_REFILL_MIN 16
+#define CRT_REFILL_MIN 8          /* closest-hit walks: 6..10 measure the same, 2 and 16 are 2 % slower */
+#endif
+#ifndef CRT_REFILL_MIN_SHADOW
+#define CRT_REFILL_MIN_SHADOW 32  /* any-hit walks are short: 28..36 measure the same, 16 and 48 are 6..9 % slower */
 #endif
 #ifndef CRT_TRI_STEP
 #define CRT_TRI_STEP 1
@@ -267,6 +270,74 @@ CRT_DEV unsigned refill(unsigned* queue_head, unsigned n, unsigned long long idl
     const unsigned idx = base + lane_rank(idle);
     return idx < n ? idx : 0xFFFFFFFFu;
 }
+
+/* ---- ray feed: lane refill without the stalls ---------------------------------------
+ * refill() above costs the whole wave two dependent trips to HBM every time it runs (the atomic
+ * on the queue head, then perm -> ray record), which shows once rays are short: the any-hit walk
+ * went from 1 330 to 1 826 Mrays/s merely by refilling half as often.  The feed takes both trips
+ * off the critical path: a wave claims 64 queue slots at a time one claim AHEAD, loads the claimed
+ * rays into registers (lane l holds slot l) as soon as the previous claim becomes current, and
+ * hands them to idle lanes through ds_bpermute -- by the time a lane asks, the data is there. */
+template <bool WITH_LD>
+struct RayFeed {
+    unsigned pend;                    /* lane 0: result of the claim issued ahead */
+    unsigned res_pos, res_cnt;        /* wave-uniform: next unread slot / slots in the current claim */
+    bool empty;                       /* wave-uniform: the queue has nothing more for this wave */
+    unsigned pre_ri; DRay pre_ray; float pre_ld;
+
+    CRT_DEV void claim(const LaunchArgs& la)
+    {
+        if ((threadIdx.x & 63) == 0) pend = atomicAdd(la.queue_head, 64u);
+    }
+    CRT_DEV void swap_in(const LaunchArgs& la)
+    {
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pend);
+        res_pos = 0;
+        res_cnt = base < la.n ? (la.n - base < 64u ? la.n - base : 64u) : 0u;
+        if (res_cnt == 0u) { empty = true; return; }
+        const unsigned lane = threadIdx.x & 63;
+        if (lane < res_cnt) {
+            const unsigned idx = base + lane;
+            pre_ri = la.perm ? la.perm[idx] : idx;
+            pre_ray = load_ray(la.rays, pre_ri);
+            if (WITH_LD) pre_ld = la.light_dist[pre_ri];
+        }
+        claim(la);
+    }
+    CRT_DEV void start(const LaunchArgs& la)
+    {
+        pend = 0; res_pos = res_cnt = 0; empty = false;
+        pre_ri = 0; pre_ld = 0.0f;
+        pre_ray.ox = pre_ray.oy = pre_ray.oz = 0.0f; pre_ray.dx = pre_ray.dy = pre_ray.dz = 1.0f;
+        claim(la);
+        swap_in(la);
+    }
+    /* idle: ballot of lanes without a ray.  Returns true for the lanes that received one. */
+    CRT_DEV bool take(const LaunchArgs& la, unsigned long long idle, bool lane_idle, unsigned* ri, DRay* ray, float* ld)
+    {
+        const unsigned cnt = (unsigned)__popcll(idle);
+        const unsigned avail = res_cnt - res_pos;
+        const unsigned n_take = cnt < avail ? cnt : avail;
+        const unsigned rank = lane_rank(idle);
+        const unsigned src = (res_pos + rank) & 63u;
+        const int a = (int)(src << 2);
+        const unsigned v_ri = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)pre_ri);
+        DRay v;
+        v.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.ox)));
+        v.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.oy)));
+        v.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.oz)));
+        v.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.dx)));
+        v.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.dy)));
+        v.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ray.dz)));
+        float v_ld = 0.0f;
+        if (WITH_LD) v_ld = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(pre_ld)));
+        const bool got = lane_idle && rank < n_take;
+        if (got) { *ri = v_ri; *ray = v; if (WITH_LD) *ld = v_ld; }
+        res_pos += n_take;
+        if (res_pos == res_cnt) swap_in(la);          /* the next claim's rays load while the wave walks */
+        return got;
+    }
+};
 
 /* =====================================================================================
  * QBVH closest hit, best-t pruned, reference child order.
@@ -299,7 +370,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
     st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
 
-    bool alive = false, queue_empty = false;
+    bool alive = false;
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
@@ -314,13 +385,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
     float cur_min = CRT_TMAX;     /* EXACT: min_t of the innermost open node visit */
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
+    RayFeed<false> feed;
+    feed.start(la);
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
-        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
-            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
-            if (idx != 0xFFFFFFFFu) {
-                ri = la.perm ? la.perm[idx] : idx;
-                ray = load_ray(la.rays, ri);
+        if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN) {
+            float unused_ld;
+            if (feed.take(la, idle, !alive, &ri, &ray, &unused_ld)) {
                 cur_min = CRT_TMAX;
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
                 const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
@@ -451,7 +522,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
     st.sp = 0;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
 
-    bool alive = false, queue_empty = false;
+    bool alive = false;
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f, ld = 0.0f, result = CRT_TMAX;
@@ -460,14 +531,12 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
     bool clean = true, wave_clean = true;
     const float ninf = -__builtin_huge_valf();
 
+    RayFeed<true> feed;
+    feed.start(la);
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
-        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
-            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
-            if (idx != 0xFFFFFFFFu) {
-                ri = la.perm ? la.perm[idx] : idx;
-                ray = load_ray(la.rays, ri);
-                ld = la.light_dist[ri];
+        if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN_SHADOW) {
+            if (feed.take(la, idle, !alive, &ri, &ray, &ld)) {
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;
                 const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
                 onx = sx ? 0u : 48u;  ofx = 48u - onx;
@@ -632,20 +701,20 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
     const float ninf = -__builtin_huge_valf();
 
-    bool alive = false, queue_empty = false, walking = false;
+    bool alive = false, walking = false;
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
     float best_t = CRT_TMAX;
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
+    RayFeed<false> feed;
+    feed.start(la);
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
-        if (idle != 0ull && !queue_empty && __popcll(idle) >= CRT_REFILL_MIN) {
-            const unsigned idx = refill(la.queue_head, la.n, idle, !alive, &queue_empty);
-            if (idx != 0xFFFFFFFFu) {
-                ri = la.perm ? la.perm[idx] : idx;
-                ray = load_ray(la.rays, ri);
+        if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN) {
+            float unused_ld;
+            if (feed.take(la, idle, !alive, &ri, &ray, &unused_ld)) {
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* aabb.cpp:94,:106,:118 */
                 best_t = CRT_TMAX;
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
