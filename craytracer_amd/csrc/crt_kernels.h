@@ -242,8 +242,8 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
  * so a wave that waits for the slowest of 64 rays runs with most lanes switched off (measured:
  * 12 % active lanes per VALU instruction, profiles/r01_pmc_baseline.txt).  Instead, lanes whose
  * ray has finished are refilled from the queue while the others keep walking: once at least
- * CRT_REFILL_MIN lanes are idle, one agent-scope atomic claims that many rays for the wave, and
- * each idle lane takes the claimed slot given by its rank among the idle lanes (ballot + mbcnt). */
+ * CRT_REFILL_MIN lanes are idle, each idle lane takes the next ray of the wave's feed (below) given
+ * by its rank among the idle lanes (ballot + mbcnt). */
 #ifndef CRT_REFILL_MIN
 #define CRT_REFILL_MIN 8          /* closest-hit walks: 6..10 measure the same, 2 and 16 are 2 % slower */
 #endif
@@ -258,23 +258,11 @@ CRT_DEV unsigned lane_rank(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
-/* Returns this lane's new ray index (or 0xFFFFFFFF); *queue_empty is wave-uniform. */
-CRT_DEV unsigned refill(unsigned* queue_head, unsigned n, unsigned long long idle, bool lane_idle, bool* queue_empty)
-{
-    const unsigned cnt = (unsigned)__popcll(idle);
-    unsigned base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(queue_head, cnt);
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (base + cnt >= n) *queue_empty = true;
-    if (!lane_idle) return 0xFFFFFFFFu;
-    const unsigned idx = base + lane_rank(idle);
-    return idx < n ? idx : 0xFFFFFFFFu;
-}
-
 /* ---- ray feed: lane refill without the stalls ---------------------------------------
- * refill() above costs the whole wave two dependent trips to HBM every time it runs (the atomic
- * on the queue head, then perm -> ray record), which shows once rays are short: the any-hit walk
- * went from 1 330 to 1 826 Mrays/s merely by refilling half as often.  The feed takes both trips
+ * Claiming rays at the moment lanes go idle costs the whole wave two dependent trips to HBM (the
+ * atomic on the queue head, then perm -> ray record), which shows once rays are short: with that
+ * scheme the any-hit walk went from 1 330 to 1 826 Mrays/s merely by refilling half as often.  The
+ * feed takes both trips
  * off the critical path: a wave claims 64 queue slots at a time one claim AHEAD, loads the claimed
  * rays into registers (lane l holds slot l) as soon as the previous claim becomes current, and
  * hands them to idle lanes through ds_bpermute -- by the time a lane asks, the data is there. */
