@@ -550,7 +550,10 @@ int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_lig
  * with ordinary malloc'd buffers HIP stages them and the calls are merely correct. */
 namespace {
 
-const size_t CRT_CHUNK_RAYS = (size_t)1 << 21;       /* 48 MB in, 40 MB out per chunk */
+#ifndef CRT_CHUNK_LOG2
+#define CRT_CHUNK_LOG2 22
+#endif
+const size_t CRT_CHUNK_RAYS = (size_t)1 << CRT_CHUNK_LOG2;       /* 2^22 rays: 96 MB in, 80 MB out per chunk (2^20 / 2^21 / 2^23 measured slower) */
 
 int ensure_chunks(crt_scene* s, size_t need, bool shadow)
 {

@@ -18,7 +18,7 @@ def setup():
     si = scenes.courtyard(8, 32, 64, seed=4)
     sc = api.Scene(api.BuiltScene(si, api.ACCEL_BVH4), 0)
     lo, hi = scenes.scene_bounds(si)
-    n = (1 << 22) + 12345                       # 3 chunks of 2^21, the last one ragged
+    n = (2 << 22) + 12345                       # 3 chunks of 2^22, the last one ragged
     rays = scenes.random_rays(n, lo, hi, 17)
     yield si, sc, rays
     sc.close()
