@@ -319,6 +319,15 @@ def main():
         t1 = time.perf_counter()
         cpu(0, m1, 1)
         cpu1_s = time.perf_counter() - t1
+        o0_mrays = None
+        if os.path.exists(ol.ORACLE_O0_PATH):        # the reference's own Makefile builds without -O (Makefile:12)
+            o_keep, o = o, ol.OracleScene(si, accel, built=built, lib_path=ol.ORACLE_O0_PATH)
+            m0 = max(m1 // 4, 1)
+            t1 = time.perf_counter()
+            cpu(0, m0, 1)
+            o0_mrays = round(m0 / (time.perf_counter() - t1) / 1e6, 4)
+            o.close()
+            o = o_keep
         if shadow:
             same = bool(ol.same_bits(d_t[:m].cpu().numpy(), ref[0])) and \
                 bool(np.array_equal(d_occ[:m].cpu().numpy().astype(bool), ref[1]))
@@ -327,7 +336,7 @@ def main():
             same = bool(ol.same_bits(gpu_hits, ref))
         out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                "sample": "first %d rays of the GPU batch, oracle in the reference's control flow, %.1f s" % (m, cpu_s),
-                               "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4),
+                               "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4), "one_thread_O0_mrays": o0_mrays,
                                "gpu_bit_identical_on_sample": same}
     if rank == 0:
         print(json.dumps(out), flush=True)

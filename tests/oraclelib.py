@@ -10,6 +10,8 @@ from craytracer_amd import api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_PATH = os.path.join(ROOT, "oracle", "libcrt_oracle.so")
+ORACLE_O0_PATH = os.path.join(ROOT, "oracle", "libcrt_oracle_O0.so")
+_oracle_by_path = {}
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libcrt_ref.so")
 
 _oracle = None
@@ -17,10 +19,26 @@ _ref = None
 vp = C.c_void_p
 
 
-def oracle():
+def oracle(path=None):
+    """The CPU checker; path=ORACLE_O0_PATH loads the -O0 build (baseline timing only)."""
     global _oracle
+    if path is not None:
+        if path not in _oracle_by_path:
+            saved, _oracle = _oracle, None
+            try:
+                _oracle_by_path[path] = _load_oracle(path)
+            finally:
+                _oracle = saved
+        return _oracle_by_path[path]
     if _oracle is None:
-        L = C.CDLL(ORACLE_PATH)
+        _oracle = _load_oracle(ORACLE_PATH)
+    return _oracle
+
+
+def _load_oracle(path):
+    global _oracle
+    if True:
+        L = C.CDLL(path)
         L.oracle_scene_create.argtypes = [C.POINTER(api.CrtSceneInput), C.c_int, C.c_int]
         L.oracle_scene_create.restype = vp
         L.oracle_scene_from_desc.argtypes = [C.POINTER(api.CrtSceneDesc)]
@@ -52,8 +70,7 @@ def oracle():
         L.oracle_film_dimension.restype = None
         L.oracle_primary_rays.argtypes = [C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm), C.c_uint, C.c_size_t, vp, vp, vp]
         L.oracle_primary_rays.restype = None
-        _oracle = L
-    return _oracle
+    return L
 
 
 def have_ref():
@@ -128,9 +145,9 @@ class _SceneBase:
 
 
 class OracleScene(_SceneBase):
-    def __init__(self, scene_input, accel=None, sort_mode=0, built=None):
+    def __init__(self, scene_input, accel=None, sort_mode=0, built=None, lib_path=None):
         """built: an api.BuiltScene to adopt (same tree as the GPU) instead of building from input."""
-        L = oracle()
+        L = oracle(lib_path)
         self.L = L
         self.input = scene_input
         if built is not None:
