@@ -89,6 +89,23 @@ class CrtCounters(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
+MAT_MATTE, MAT_EMISSIVE = 1, 8                      # MatType, materials.h:8-18
+MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity", "<f4"), ("sigma", "<f4")])
+assert MATERIAL_DTYPE.itemsize == 24
+
+
+class CrtRenderDesc(C.Structure):
+    _fields_ = [("objects", C.c_void_p), ("obj_material", C.c_void_p), ("materials", C.c_void_p), ("num_materials", C.c_int32),
+                ("has_env_light", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_float),
+                ("env_world_radius", C.c_float), ("max_depth", C.c_int32), ("samples_in_flight", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class CrtRenderStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shadow", C.c_double)]
+
+
 # every symbol include/crt_gpu.h declares
 EXPORTS = [
     "crt_build_scene", "crt_built_scene_desc", "crt_built_scene_destroy",
@@ -99,6 +116,8 @@ EXPORTS = [
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
+    "crt_scene_device", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
+    "crt_renderer_get_stats",
 ]
 
 _lib = None
@@ -152,6 +171,13 @@ def lib():
     L.crt_scene_reset_counters.argtypes = [vp]
     L.crt_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.crt_scene_last_binning_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crt_scene_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.crt_renderer_create.argtypes = [vp, C.POINTER(CrtRenderDesc), C.POINTER(CrtCamera), C.POINTER(CrtFilm), C.POINTER(vp)]
+    L.crt_renderer_destroy.argtypes = [vp]
+    L.crt_renderer_destroy.restype = None
+    L.crt_renderer_render.argtypes = [vp, C.c_uint32]
+    L.crt_renderer_read.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.crt_renderer_get_stats.argtypes = [vp, C.POINTER(CrtRenderStats)]
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_strerror.restype = C.c_char_p
     L.crt_last_hip_error.argtypes = []
@@ -264,6 +290,78 @@ class SceneInput:
         s.shapes = _ptr(self.shapes)
         s.num_shapes = len(self.shapes)
         return s
+
+
+class RenderDesc:
+    """Materials, lights and limits of the restricted path tracer (crt_render_desc).  Keeps the numpy
+    arrays alive; `.c` is the ctypes struct."""
+
+    def __init__(self, scene_input, obj_material, materials, max_depth, seed=0, env=None, samples_in_flight=0):
+        self.scene_input = scene_input
+        self._in = scene_input.c_struct()
+        self.obj_material = np.ascontiguousarray(obj_material, dtype=np.int32)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        assert len(self.obj_material) == scene_input.num_obj
+        c = CrtRenderDesc()
+        c.objects = C.addressof(self._in)
+        c.obj_material = _ptr(self.obj_material)
+        c.materials = _ptr(self.materials)
+        c.num_materials = len(self.materials)
+        if env is not None:                       # (color[3], intensity, world_radius)
+            c.has_env_light = 1
+            c.env_color = (C.c_float * 3)(*[float(x) for x in env[0]])
+            c.env_intensity = float(env[1])
+            c.env_world_radius = float(env[2])
+        c.max_depth = int(max_depth)
+        c.samples_in_flight = int(samples_in_flight)
+        c.seed = int(seed)
+        self.c = c
+
+
+def material(type_, color, intensity=0.0, sigma=0.0):
+    m = np.zeros(1, MATERIAL_DTYPE)[0]
+    m["type"] = type_
+    m["color"] = np.asarray(color, np.float32)
+    m["intensity"] = intensity
+    m["sigma"] = sigma
+    return m
+
+
+class Renderer:
+    """crt_renderer: wavefront path tracing over a Scene (restricted form)."""
+
+    def __init__(self, scene, desc, cam, film):
+        self._scene, self._desc = scene, desc             # the C side keeps a pointer to the scene
+        self.width, self.height = film.frame_res_width, film.frame_res_height
+        self._h = C.c_void_p()
+        _check(lib().crt_renderer_create(scene._h, C.byref(desc.c), C.byref(cam), C.byref(film), C.byref(self._h)),
+               "crt_renderer_create")
+
+    def render(self, num_samples):
+        _check(lib().crt_renderer_render(self._h, int(num_samples)), "crt_renderer_render")
+
+    def read(self):
+        """(color_buffer [h, w, 3] = running sum of samples, num_samples)"""
+        buf = np.zeros((self.height, self.width, 3), np.float32)
+        n = C.c_uint32()
+        _check(lib().crt_renderer_read(self._h, buf.ctypes.data, C.byref(n)), "crt_renderer_read")
+        return buf, n.value
+
+    def stats(self):
+        st = CrtRenderStats()
+        _check(lib().crt_renderer_get_stats(self._h, C.byref(st)), "crt_renderer_get_stats")
+        return {k: getattr(st, k) for k, _ in CrtRenderStats._fields_}
+
+    def close(self):
+        if self._h:
+            lib().crt_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _view(ptr, n, dtype):

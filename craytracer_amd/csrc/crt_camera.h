@@ -12,6 +12,7 @@
 #else
 #define CRT_HD inline
 #endif
+#include "crt_libm.h"
 
 CRT_HD void cam_normalize(float* r, const float* a)
 {
@@ -46,7 +47,7 @@ CRT_HD void cam_ray_thin_lens(crt_ray* ray, const float* vp, const crt_camera& c
 {
     const float phi = (float)(2.0f * M_PI * (double)s0);     /* `2.0f * M_PI * in[0]` is a double product, narrowed on assignment */
     const float radius = sqrtf(s1);
-    const float dx = cosf(phi) * radius, dy = sinf(phi) * radius;
+    const float dx = crt_libm_cosf(phi) * radius, dy = crt_libm_sinf(phi) * radius;          /* glibc's values to the bit: crt_libm.h */
     const float ratio = c.focal_length / c.focal_pt_dist;
     const float fpp[3] = { vp[0] * ratio, vp[1] * ratio, -c.focal_length };
     const float o[3] = { dx * c.lens_radius, dy * c.lens_radius, c.focal_pt_dist };

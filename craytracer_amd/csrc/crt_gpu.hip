@@ -490,6 +490,13 @@ void crt_scene_destroy(crt_scene* s)
     free_scene(s);
 }
 
+int crt_scene_device(const crt_scene* s, int* device)
+{
+    if (!s || !device) return CRT_E_INVALID;
+    *device = s->device;
+    return CRT_OK;
+}
+
 int crt_scene_set_traverse_mode(crt_scene* s, int mode)
 {
     if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;

@@ -1,0 +1,618 @@
+/*
+ * crt_render.hip -- wavefront path tracing on top of the ray-query ABI (restricted form).
+ *
+ * The reference traces one path per call: pathTrace (trace.h:399-532) loops over bounces and calls
+ * intersectTest once per bounce and, through uniformSampleOneLight / estimateDirect (trace.h:359-397,
+ * :221-357), shadowIntersectTest once per bounce.  Here every live path advances one bounce per
+ * kernel: the rays of all paths go through crt_intersect_batch_dev, a shading kernel rebuilds the
+ * ShadeRec of each hit (the tail of the reference's intersectors: triangle.cpp:154-168,:185-204,
+ * rect.cpp:34-46, sphere.cpp:3-31), samples one light and the BSDF, and appends a shadow ray and the
+ * next path ray to device queues; the shadow rays go through crt_shadow_batch_dev and their
+ * unoccluded contributions are added.  The sample loop of threadFunc (main.cpp:88-149) is the outer
+ * loop.  This file is a client of include/crt_gpu.h like any other caller; it sees no scene internals.
+ *
+ * Arithmetic follows the reference operation by operation (float32, separate multiply / add; double
+ * where the reference's expressions are double because PI / INV_PI are, util/vec.h:6-10).
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <stdio.h>
+#include <chrono>
+#include <new>
+#include <vector>
+
+#include "../../include/crt_gpu.h"
+#include "crt_camera.h"
+#include "crt_libm.h"
+
+namespace {
+
+#define RD_PI      3.14159265358979323846264338327950288         /* util/vec.h:6 */
+#define RD_INV_PI  (1.0 / RD_PI)                                  /* util/vec.h:10 */
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 v3p(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       /* util/vec.h:154 */
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float length(V3 a) { return (float)sqrt((double)dot(a, a)); }             /* util/vec.h:240 */
+__device__ __forceinline__ V3 normalize(V3 a)                                                          /* util/vec.h:206-215 */
+{
+    const float len = (float)sqrt((double)dot(a, a));
+    if (len == 0) return v3(0.f, 0.f, 0.f);
+    return scale(a, 1.0f / len);
+}
+__device__ __forceinline__ bool is_black(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }  /* vec3_equal(a, BLACK) */
+/* orthoNormalTransform, util/math.cpp:10-18 */
+__device__ __forceinline__ V3 ortho(V3 u, V3 v, V3 w, V3 a) { return add(add(scale(u, a.x), scale(v, a.y)), scale(w, a.z)); }
+/* getVec3InLocalBasis, util/math.cpp:31-39; JITTERED_UP, util/constants.h:27 */
+__device__ __forceinline__ V3 jittered_up() { return v3(0.0072f, 1.0f, 0.0034f); }
+__device__ __forceinline__ V3 in_local_basis(V3 a, V3 normal)
+{
+    const V3 w = normal;
+    const V3 v = normalize(cross(w, jittered_up()));
+    const V3 u = cross(v, w);
+    return ortho(u, v, w, a);
+}
+/* mapSampleToDisk / mapSampleToHemisphere, sampling.cpp:606-618 */
+__device__ __forceinline__ void sample_disk(float* out, float s0, float s1)
+{
+    const float phi = (float)(2.0f * M_PI * (double)s0);
+    const float radius = sqrtf(s1);
+    out[0] = crt_libm_cosf(phi) * radius;                          /* glibc's values to the bit: crt_libm.h */
+    out[1] = crt_libm_sinf(phi) * radius;
+}
+__device__ __forceinline__ V3 sample_hemisphere(float s0, float s1)
+{
+    float d[2];
+    sample_disk(d, s0, s1);
+    const float zz = 1.0f - d[0] * d[0] - d[1] * d[1];
+    return v3(d[0], d[1], sqrtf((0.0f > zz) ? 0.0f : zz));            /* max(0, .), util/util.h:14 */
+}
+
+/* crt_rng: DESIGN.md "N1".  Three rounds of the murmur3 finaliser over (seed, pixel, sample, dim). */
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ float crt_rng(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel, uint32_t sample, uint32_t dim)
+{
+    uint32_t h = fmix32(pixel ^ seed_lo);
+    h = fmix32(h + sample * 0x9E3779B1u + seed_hi);
+    h = fmix32(h ^ (dim * 0x85EBCA77u + 0x165667B1u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+enum { DIM_IMAGE = 0, DIM_LENS = 2, DIM_BOUNCE0 = 4, DIMS_PER_BOUNCE = 8,
+       DIM_LIGHT = 0, DIM_SCATTER = 2, DIM_BSDF = 4, DIM_PICK = 6, DIM_RR = 7 };
+
+/* per-object shading record, indexed by insertion id (crt_hit.obj) */
+struct ShadeObj {
+    int32_t type, mat;
+    float p[14];      /* TRIANGLE / FLAT: normal[3] tangent[3] | RECTANGLE: normal[3] dpdu[3] point[3] | SPHERE: center[3] radius */
+};
+enum { LIGHT_ENV = 0, LIGHT_AREA = 1 };
+struct LightRec {
+    int32_t kind, obj_type;
+    float color[3], intensity, power, pad;
+    float p[12];      /* RECTANGLE: point width height normal | SPHERE: center radius | DISK: center normal radius */
+};
+
+struct RenderDev {
+    const ShadeObj* objs; const crt_material* mats; const LightRec* lights;
+    int32_t num_lights, has_env, max_depth;
+    float env_color[3], env_intensity, env_world_radius;
+    uint32_t seed_lo, seed_hi, npix;
+    crt_camera cam; crt_film film;
+    /* per path */
+    float* beta; float* L; uint32_t* good;
+    /* queues */
+    crt_ray* rays[2]; uint32_t* qpath[2]; crt_hit* hits;
+    crt_ray* srays; float* sdist; uint32_t* spath; float* scontrib; uint8_t* socc;
+    uint32_t* counters;                   /* [0] rays queued for the next bounce, [1] shadow rays queued */
+    float* color;                         /* [npix*3] running sum, main.cpp:139-141 */
+};
+
+/* one atomic per wave: returns this lane's slot when `want`, any value otherwise; all 64 lanes must call */
+__device__ __forceinline__ unsigned queue_push(unsigned* counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0;
+    const unsigned lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+/* threadFunc's per-pixel head, main.cpp:102-115: two Sampler_getSample values, calcImageCoord, calcCameraRay */
+__global__ __launch_bounds__(256) void k_pt_generate(RenderDev rd, unsigned num_paths, unsigned first_sample)
+{
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= num_paths) return;
+    const unsigned pixel = p % rd.npix, sample = first_sample + p / rd.npix;
+    const float i0 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_IMAGE), i1 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_IMAGE + 1);
+    const float l0 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_LENS), l1 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_LENS + 1);
+    crt_ray ray;
+    cam_primary_ray(&ray, rd.cam, rd.film, pixel, i0, i1, l0, l1);
+    rd.rays[0][p] = ray;
+    rd.qpath[0][p] = p;
+    rd.beta[3 * (size_t)p] = 1.0f; rd.beta[3 * (size_t)p + 1] = 1.0f; rd.beta[3 * (size_t)p + 2] = 1.0f;   /* trace.h:405-406 */
+    rd.L[3 * (size_t)p] = 0.0f; rd.L[3 * (size_t)p + 1] = 0.0f; rd.L[3 * (size_t)p + 2] = 0.0f;
+    rd.good[p] = 0;
+}
+
+/* One iteration of pathTrace's loop body (trace.h:413-527) for every queued path, minus the two
+ * scene queries: the closest hit arrives in hits[], the shadow query leaves through the shadow queue. */
+__global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int bounce, int cur, unsigned first_sample)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    bool push_shadow = false, push_next = false;
+    crt_ray sray, nray; float sdist = 0.f; V3 scontrib = v3(0.f, 0.f, 0.f);
+    unsigned p = 0;
+    if (active) {
+        p = rd.qpath[cur][i];
+        const crt_ray ray = rd.rays[cur][i];
+        const crt_hit hit = rd.hits[i];
+        const unsigned pixel = p % rd.npix, samp = first_sample + p / rd.npix;
+        V3 beta = v3p(rd.beta + 3 * (size_t)p);
+        V3 L = v3p(rd.L + 3 * (size_t)p);
+        unsigned good = rd.good[p];
+        const bool is_hit = hit.obj >= 0;
+        ShadeObj so; so.type = -1; so.mat = 0;
+        crt_material mat; mat.type = 0;
+        if (is_hit) { so = rd.objs[hit.obj]; mat = rd.mats[so.mat]; }
+        /* emitted / environment light: bounce 0 only -- a Lambertian lobe never sets the SPECULAR or
+         * GLOSSY flag that re-enables it on later bounces (trace.h:419) */
+        if (bounce == 0) {
+            if (is_hit) {
+                if (mat.type == CRT_MAT_EMISSIVE) {
+                    V3 inc = scale(v3p(mat.color), mat.intensity);
+                    inc = mul(inc, beta);
+                    L = add(L, inc);
+                    good++;
+                }
+            } else {
+                V3 env = v3(0.f, 0.f, 0.f);                       /* the reference leaves it uninitialised without an env light */
+                if (rd.has_env) env = scale(v3p(rd.env_color), rd.env_intensity);    /* getEnvLightIncRadiance CONSTANT, lights.cpp:233-238 */
+                env = mul(env, beta);
+                L = add(L, env);
+                good++;
+            }
+        }
+        bool alive = is_hit && bounce < rd.max_depth && mat.type != CRT_MAT_EMISSIVE;    /* trace.h:459 */
+        if (alive) {
+            /* ---- ShadeRec ---- */
+            const V3 ro = v3p(ray.o), rdir = v3p(ray.d);
+            const V3 hp = add(ro, scale(rdir, hit.t));            /* getPointOnRay, util/ray.cpp:4-9 */
+            const V3 wo = neg(rdir);
+            V3 normal, dpdu;
+            if (so.type == CRT_TRIANGLE) {                        /* triangle.cpp:159-166 */
+                normal = v3p(so.p); dpdu = v3p(so.p + 3);
+                if (dot(wo, normal) < 0.0f) normal = neg(normal);
+            } else if (so.type == CRT_FLAT_TRIANGLE) {            /* triangle.cpp:199-202: not flipped */
+                normal = v3p(so.p); dpdu = v3p(so.p + 3);
+            } else if (so.type == CRT_RECTANGLE) {                /* rect.cpp:5-16,:34-46 */
+                const V3 rn = v3p(so.p);
+                const V3 disp = sub(v3p(so.p + 6), ro);
+                normal = dot(disp, rn) < 0.0f ? neg(rn) : rn;
+                dpdu = v3p(so.p + 3);
+                if (dot(wo, normal) < 0.0f) { normal = neg(normal); dpdu = neg(dpdu); }
+            } else {                                              /* SPHERE, sphere.cpp:7-10,:25-29 */
+                const V3 c = v3p(so.p);
+                normal = normalize(sub(hp, c));
+                const double phi_max = 2.0 * RD_PI;
+                dpdu = normalize(v3((float)(-phi_max * (double)(hp.z - c.z)), 0.0f, (float)(phi_max * (double)(hp.x - c.x))));
+            }
+            /* ---- computeLocalBasis, trace.h:132-146 ---- */
+            V3 tangent = dpdu;
+            const float dp = dot(normal, tangent);
+            if (dp != 0.0f) tangent = normalize(sub(tangent, scale(normal, dp)));
+            const V3 binormal = normalize(cross(normal, tangent));
+            /* ---- computeScatteringFunc: MATTE, sigma 0 -> one Lambertian (materials.cpp:116-124) ---- */
+            const V3 cd = v3p(mat.color);
+            const unsigned dim0 = DIM_BOUNCE0 + DIMS_PER_BOUNCE * (unsigned)bounce;
+            #define RNG(d) crt_rng(rd.seed_lo, rd.seed_hi, pixel, samp, dim0 + (d))
+            const float ls0 = RNG(DIM_LIGHT), ls1 = RNG(DIM_LIGHT + 1);
+            /* scatter_sample (trace.h:469) is drawn and never used: dimensions DIM_SCATTER, +1 stay reserved */
+            /* ---- uniformSampleOneLight, trace.h:359-397 ---- */
+            if (rd.num_lights > 0) {
+                const float u = RNG(DIM_PICK);
+                int li = rd.num_lights - 1;                       /* the reference leaves light_index unset when no interval matches */
+                float sel_pdf = rd.lights[li].power;
+                float cdf = 0.0f;
+                for (int k = 0; k < rd.num_lights; k++) {
+                    const float pw = rd.lights[k].power;
+                    if (cdf <= u && cdf + pw > u) { li = k; sel_pdf = pw; break; }
+                    cdf += pw;
+                }
+                const LightRec lt = rd.lights[li];
+                /* ---- estimateDirect, trace.h:221-357 ---- */
+                V3 sp, sn, wi; float lpdf;
+                if (lt.kind == LIGHT_AREA) {
+                    if (lt.obj_type == CRT_SPHERE) {
+                        const V3 c = v3p(lt.p); const float radius = lt.p[3];
+                        const V3 z_axis = normalize(sub(hp, c));
+                        V3 h = sample_hemisphere(ls0, ls1);
+                        h = in_local_basis(h, z_axis);
+                        sp = add(scale(h, radius), c);
+                        sn = h;
+                        lpdf = (float)(1.0f / (2.0f * RD_PI * (double)radius * (double)radius) * (double)fabsf(dot(h, z_axis)) * RD_INV_PI);
+                    } else if (lt.obj_type == CRT_RECTANGLE) {
+                        const V3 pt = v3p(lt.p), w = v3p(lt.p + 3), hgt = v3p(lt.p + 6);
+                        sp = add(add(pt, scale(w, ls0)), scale(hgt, ls1));
+                        sn = v3p(lt.p + 9);
+                        lpdf = 1.0f / (length(w) * length(hgt));
+                    } else {                                      /* DISK */
+                        const V3 c = v3p(lt.p), dn = v3p(lt.p + 3); const float radius = lt.p[6];
+                        float ds[2];
+                        sample_disk(ds, ls0, ls1);
+                        const V3 x_axis = normalize(cross(jittered_up(), dn));
+                        const V3 y_axis = cross(x_axis, dn);
+                        sp = add(add(scale(x_axis, ds[0] * radius), scale(y_axis, ds[1] * radius)), c);
+                        sn = dn;
+                        lpdf = (float)(1.0f / (RD_PI * (double)radius * (double)radius));
+                    }
+                    const V3 s2h = sub(sp, hp);
+                    wi = normalize(s2h);
+                    lpdf *= dot(s2h, s2h) / fabsf(dot(sn, neg(wi)));
+                } else {                                          /* ENVLIGHT, identity transform */
+                    V3 h = sample_hemisphere(ls0, ls1);
+                    h = ortho(tangent, binormal, normal, h);
+                    sp = add(hp, scale(h, rd.env_world_radius));
+                    sn = neg(h);
+                    wi = h;
+                    lpdf = (float)((double)fabsf(dot(h, normal)) * RD_INV_PI);
+                }
+                const V3 Li = scale(v3p(lt.color), lt.intensity);
+                const V3 s2h = sub(sp, hp);
+                if (!(dot(s2h, sn) > 0.0f || dot(s2h, normal) < 0.0f) && lpdf > 0.0f && !is_black(Li)) {
+                    V3 f = scale(cd, (float)RD_INV_PI);           /* Lambertian_f, reflection.cpp:159-163 */
+                    f = scale(f, fabsf(dot(normal, wi)));
+                    if (!is_black(f)) {
+                        V3 radiance = mul(f, Li);
+                        radiance = scale(radiance, 1.0f / lpdf);
+                        V3 contrib = scale(radiance, 1.0f / sel_pdf);     /* trace.h:396 */
+                        contrib = mul(contrib, beta);                      /* trace.h:474 */
+                        push_shadow = true;
+                        sdist = length(s2h);
+                        sray.o[0] = hp.x; sray.o[1] = hp.y; sray.o[2] = hp.z;
+                        sray.d[0] = wi.x; sray.d[1] = wi.y; sray.d[2] = wi.z;
+                        scontrib = contrib;
+                    }
+                }
+            }
+            /* ---- BSDF_sample_f (reflection.cpp:750-811) with the one Lambertian lobe ---- */
+            const float bs0 = RNG(DIM_BSDF), bs1 = RNG(DIM_BSDF + 1);
+            const V3 wo_l = v3(dot(wo, tangent), dot(wo, binormal), dot(wo, normal));    /* transposeTransform */
+            alive = false;
+            if (wo_l.z != 0.0f) {
+                const float two_z = fabsf(wo_l.z);                /* Lambertian_sample_f flips tmp_wo into the upper hemisphere */
+                V3 f = scale(cd, (float)RD_INV_PI);
+                const V3 wi_l = sample_hemisphere(bs0, bs1);
+                const float pdf = (wi_l.z * two_z > 0.0f) ? (float)((double)fabsf(wi_l.z) * RD_INV_PI) : 0.0f;   /* cosHemispherePdf */
+                if (pdf != 0.0f && !is_black(f)) {
+                    const V3 wi = ortho(tangent, binormal, normal, wi_l);
+                    f = scale(f, fabsf(dot(wi, normal)) / pdf);   /* trace.h:494 */
+                    beta = mul(beta, f);
+                    alive = true;
+                    if (bounce > 3) {                             /* Russian roulette, trace.h:512-525 */
+                        const float m12 = (beta.y > beta.z) ? beta.y : beta.z;
+                        const float max_comp = (beta.x > m12) ? beta.x : m12;
+                        const float omc = 1.0f - max_comp;
+                        const float q = (0.05f > omc) ? 0.05f : omc;
+                        const float rr = RNG(DIM_RR);
+                        if (rr < q) alive = false;
+                        else beta = scale(beta, 1.0f / (1.0f - q));
+                    }
+                    if (alive) {
+                        push_next = true;
+                        nray.o[0] = hp.x; nray.o[1] = hp.y; nray.o[2] = hp.z;
+                        nray.d[0] = wi.x; nray.d[1] = wi.y; nray.d[2] = wi.z;
+                    }
+                }
+            }
+            #undef RNG
+        }
+        rd.beta[3 * (size_t)p] = beta.x; rd.beta[3 * (size_t)p + 1] = beta.y; rd.beta[3 * (size_t)p + 2] = beta.z;
+        rd.L[3 * (size_t)p] = L.x; rd.L[3 * (size_t)p + 1] = L.y; rd.L[3 * (size_t)p + 2] = L.z;
+        rd.good[p] = good;
+    }
+    const unsigned ss = queue_push(rd.counters + 1, push_shadow);
+    if (push_shadow) {
+        rd.srays[ss] = sray; rd.sdist[ss] = sdist; rd.spath[ss] = p;
+        rd.scontrib[3 * (size_t)ss] = scontrib.x; rd.scontrib[3 * (size_t)ss + 1] = scontrib.y; rd.scontrib[3 * (size_t)ss + 2] = scontrib.z;
+    }
+    const unsigned ns = queue_push(rd.counters + 0, push_next);
+    if (push_next) { rd.rays[cur ^ 1][ns] = nray; rd.qpath[cur ^ 1][ns] = p; }
+}
+
+/* tail of estimateDirect / pathTrace's direct-light step: `if(!in_shadow)` (trace.h:348-355), then
+ * L += contrib and good_paths++ when contrib is not black (trace.h:475-477) */
+__global__ __launch_bounds__(256) void k_pt_accumulate(RenderDev rd, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (rd.socc[i]) return;
+    const unsigned p = rd.spath[i];
+    const V3 c = v3p(rd.scontrib + 3 * (size_t)i);
+    rd.L[3 * (size_t)p] += c.x; rd.L[3 * (size_t)p + 1] += c.y; rd.L[3 * (size_t)p + 2] += c.z;
+    if (!is_black(c)) rd.good[p] += 1;
+}
+
+/* end of pathTrace (trace.h:528-530) and of threadFunc's per-pixel body (main.cpp:125-141), for the
+ * `spp` samples of this pass in sample order */
+__global__ __launch_bounds__(256) void k_pt_finish(RenderDev rd, unsigned spp, unsigned first_sample)
+{
+    const unsigned pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= rd.npix) return;
+    V3 buf = v3p(rd.color + 3 * (size_t)pixel);
+    for (unsigned s = 0; s < spp; s++) {
+        const size_t p = (size_t)s * rd.npix + pixel;
+        V3 L = v3p(rd.L + 3 * p);
+        const unsigned good = rd.good[p];
+        if (good > 0) L = scale(L, 1.0f / (float)(int)good);
+        V3 color = add(v3(0.f, 0.f, 0.f), L);
+        if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z))
+            color = scale(buf, 1 / (float)(first_sample + s + 1));      /* main.cpp:133-135 */
+        buf = add(buf, color);
+    }
+    rd.color[3 * (size_t)pixel] = buf.x; rd.color[3 * (size_t)pixel + 1] = buf.y; rd.color[3 * (size_t)pixel + 2] = buf.z;
+}
+
+} // namespace
+
+struct crt_renderer {
+    crt_scene* scene;
+    int device;
+    RenderDev rd;
+    uint32_t spp_max;          /* samples in flight */
+    size_t path_cap;
+    uint64_t samples;
+    crt_render_stats stats;
+    hipStream_t stream;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+struct DevGuard {
+    int prev;
+    explicit DevGuard(int dev) : prev(-1) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+template <class T>
+int dev_alloc(crt_renderer* r, T** out, size_t count)
+{
+    void* p = 0;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 256;
+    if (hipMalloc(&p, bytes) != hipSuccess) return CRT_E_NOMEM;
+    r->allocs.push_back(p);
+    *out = (T*)p;
+    return CRT_OK;
+}
+
+void host_normalize(float* r, const float* a) { cam_normalize(r, a); }
+void host_cross(float* r, const float* a, const float* b)
+{
+    r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+}
+float host_length(const float* a) { return (float)sqrt((double)(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])); }
+
+} // namespace
+
+extern "C" {
+
+void crt_renderer_destroy(crt_renderer* r)
+{
+    if (!r) return;
+    DevGuard g(r->device);
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    for (void* p : r->allocs) (void)hipFree(p);
+    delete r;
+}
+
+int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_camera* cam, const crt_film* film, crt_renderer** out)
+{
+    if (!out) return CRT_E_INVALID;
+    *out = 0;
+    if (!scene || !d || !cam || !film || !d->objects) return CRT_E_INVALID;
+    const crt_scene_input* in = d->objects;
+    if (in->num_obj < 0 || d->num_materials < 0 || d->max_depth < 0) return CRT_E_INVALID;
+    if (in->num_obj > 0 && (!d->obj_material || !d->materials)) return CRT_E_INVALID;
+    if (film->frame_res_width < 1 || film->frame_res_height < 1) return CRT_E_INVALID;
+    const unsigned long long npix64 = (unsigned long long)film->frame_res_width * (unsigned long long)film->frame_res_height;
+    if (npix64 > (1ull << 28)) return CRT_E_TOOBIG;
+    if (4 + 8ull * ((unsigned long long)d->max_depth + 1) > 0xFFFFFFFFull) return CRT_E_TOOBIG;
+    for (int m = 0; m < d->num_materials; m++) {
+        const crt_material& mt = d->materials[m];
+        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE) return CRT_E_UNSUPPORTED;
+        if (mt.type == CRT_MAT_MATTE && mt.sigma != 0.0f) return CRT_E_UNSUPPORTED;       /* Oren-Nayar */
+    }
+    std::vector<ShadeObj> objs((size_t)in->num_obj);
+    std::vector<LightRec> lights;
+    if (d->has_env_light) {                                       /* the scene file's ENV_LIGHT precedes the objects: light 0 */
+        LightRec l; memset(&l, 0, sizeof l);
+        l.kind = LIGHT_ENV; l.obj_type = -1;
+        memcpy(l.color, d->env_color, sizeof l.color);
+        l.intensity = d->env_intensity;
+        l.power = (d->env_color[0] + d->env_color[1] + d->env_color[2]) / 3.0f;            /* buildscene.h:894-895 */
+        l.power *= d->env_intensity * d->env_world_radius;
+        lights.push_back(l);
+    }
+    for (int i = 0; i < in->num_obj; i++) {
+        const int type = in->obj_type ? in->obj_type[i] : CRT_SMOOTH_TRIANGLE;
+        const int ref = in->obj_ref ? in->obj_ref[i] : i;
+        const int mi = d->obj_material[i];
+        if (mi < 0 || mi >= d->num_materials) return CRT_E_INVALID;
+        const crt_material& mt = d->materials[mi];
+        ShadeObj so; memset(&so, 0, sizeof so);
+        so.type = type; so.mat = mi;
+        if (type == CRT_TRIANGLE || type == CRT_FLAT_TRIANGLE) {
+            if (ref < 0 || ref >= in->num_tris || !in->tri_verts) return CRT_E_INVALID;
+            const float* v = in->tri_verts + 9 * (size_t)ref;
+            const float e1[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, e2[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
+            float c[3];
+            host_cross(c, e1, e2);
+            host_normalize(so.p, c);                              /* calcTriangleNormal, triangle.cpp:4-12 */
+            host_normalize(so.p + 3, e1);                         /* dpdu: the reference leaves it unset for these two types; see DESIGN.md "N1" */
+        } else if (type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) {
+            if (ref < 0 || ref >= in->num_shapes || !in->shapes || in->shapes[ref].type != type) return CRT_E_INVALID;
+            const float* sp = in->shapes[ref].p;
+            if (type == CRT_RECTANGLE) {
+                memcpy(so.p, sp + 9, 12);                         /* normal */
+                host_normalize(so.p + 3, sp + 3);                 /* dpdu = normalize(width), rect.cpp:35 */
+                memcpy(so.p + 6, sp, 12);                         /* point */
+            } else if (type == CRT_SPHERE) {
+                memcpy(so.p, sp, 16);                             /* center, radius */
+            } else if (mt.type != CRT_MAT_EMISSIVE) {
+                return CRT_E_UNSUPPORTED;                         /* disk.cpp:15-22 leaves the normal of a back-side hit unset */
+            }
+            if (mt.type == CRT_MAT_EMISSIVE) {                    /* initAreaLights, buildscene.h:567-608 */
+                LightRec l; memset(&l, 0, sizeof l);
+                l.kind = LIGHT_AREA; l.obj_type = type;
+                memcpy(l.color, mt.color, sizeof l.color);
+                l.intensity = mt.intensity;
+                float area;
+                if (type == CRT_SPHERE) { memcpy(l.p, sp, 16); area = (float)(4.0f * RD_PI * (double)sp[3] * (double)sp[3]); }
+                else if (type == CRT_RECTANGLE) { memcpy(l.p, sp, 48); area = host_length(sp + 3) * host_length(sp + 6); }
+                else { memcpy(l.p, sp, 28); area = (float)(RD_PI * (double)sp[6] * (double)sp[6]); }
+                l.power = (l.color[0] * l.color[1] * l.color[2]) / 3.0f * l.intensity * area;   /* buildscene.h:914-915 (a product, as written there) */
+                lights.push_back(l);
+            }
+        } else {
+            return CRT_E_UNSUPPORTED;
+        }
+        objs[(size_t)i] = so;
+    }
+    if (lights.size() > 0x7FFFFFFFu) return CRT_E_TOOBIG;
+    float total_power = 0.0f;
+    for (const LightRec& l : lights) total_power += l.power;
+    for (LightRec& l : lights) l.power /= total_power;            /* buildscene.h:921-922 */
+
+    int device = 0;
+    int rc = crt_scene_device(scene, &device);
+    if (rc != CRT_OK) return rc;
+    crt_renderer* r = new (std::nothrow) crt_renderer();
+    if (!r) return CRT_E_NOMEM;
+    r->scene = scene; r->device = device; r->samples = 0; r->stream = 0;
+    memset(&r->stats, 0, sizeof r->stats);
+    memset(&r->rd, 0, sizeof r->rd);
+    DevGuard g(device);
+    const uint32_t npix = (uint32_t)npix64;
+    uint32_t spp = d->samples_in_flight;
+    if (spp == 0) { spp = (uint32_t)((1u << 22) / npix); if (spp < 1) spp = 1; }
+    if ((unsigned long long)spp * npix > 0x40000000ull) { delete r; return CRT_E_TOOBIG; }
+    r->spp_max = spp;
+    r->path_cap = (size_t)spp * npix;
+    const size_t P = r->path_cap;
+    RenderDev& rd = r->rd;
+    ShadeObj* d_objs = 0; crt_material* d_mats = 0; LightRec* d_lights = 0;
+    rc = dev_alloc(r, &d_objs, objs.size());
+    if (rc == CRT_OK) rc = dev_alloc(r, &d_mats, (size_t)d->num_materials);
+    if (rc == CRT_OK) rc = dev_alloc(r, &d_lights, lights.size());
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.beta, 3 * P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.L, 3 * P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.good, P);
+    for (int k = 0; k < 2 && rc == CRT_OK; k++) { rc = dev_alloc(r, &rd.rays[k], P); if (rc == CRT_OK) rc = dev_alloc(r, &rd.qpath[k], P); }
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.hits, P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.srays, P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.sdist, P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.spath, P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.scontrib, 3 * P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.socc, P);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.counters, (size_t)64);
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.color, 3 * (size_t)npix);
+    bool ok = rc == CRT_OK;
+    ok = ok && hipMemcpy(d_objs, objs.data(), objs.size() * sizeof(ShadeObj), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d_mats, d->materials, (size_t)d->num_materials * sizeof(crt_material), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(rd.counters, 0, 256) == hipSuccess;
+    ok = ok && hipStreamCreate(&r->stream) == hipSuccess;
+    if (!ok) { crt_renderer_destroy(r); return rc != CRT_OK ? rc : CRT_E_HIP; }
+    rd.objs = d_objs; rd.mats = d_mats; rd.lights = d_lights;
+    rd.num_lights = (int32_t)lights.size();
+    rd.has_env = d->has_env_light ? 1 : 0;
+    rd.max_depth = d->max_depth;
+    memcpy(rd.env_color, d->env_color, sizeof rd.env_color);
+    rd.env_intensity = d->env_intensity; rd.env_world_radius = d->env_world_radius;
+    rd.seed_lo = (uint32_t)d->seed; rd.seed_hi = (uint32_t)(d->seed >> 32);
+    rd.npix = npix; rd.cam = *cam; rd.film = *film;
+    *out = r;
+    return CRT_OK;
+}
+
+int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
+{
+    if (!r) return CRT_E_INVALID;
+    if (r->samples + num_samples > 0xFFFFFFF0ull) return CRT_E_TOOBIG;
+    DevGuard g(r->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t st = r->stream;
+    RenderDev& rd = r->rd;
+    uint32_t done = 0;
+    while (done < num_samples) {
+        const uint32_t spp = num_samples - done < r->spp_max ? num_samples - done : r->spp_max;
+        const uint32_t first_sample = (uint32_t)r->samples;
+        const unsigned P = spp * rd.npix;
+        hipLaunchKernelGGL(k_pt_generate, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, first_sample);
+        unsigned n = P; int cur = 0;
+        for (int bounce = 0; bounce <= rd.max_depth && n > 0; bounce++) {
+            int rc = crt_intersect_batch_dev(r->scene, rd.rays[cur], n, rd.hits, st);
+            if (rc != CRT_OK) return rc;
+            float ms = 0.f;
+            if (crt_scene_last_kernel_ms(r->scene, &ms) == CRT_OK) r->stats.ms_extend += ms;
+            r->stats.rays_closest += n;
+            if (hipMemsetAsync(rd.counters, 0, 8, st) != hipSuccess) return CRT_E_HIP;
+            hipLaunchKernelGGL(k_pt_shade, dim3((n + 255) / 256), dim3(256), 0, st, rd, n, bounce, cur, first_sample);
+            uint32_t cnt[2] = { 0, 0 };
+            if (hipMemcpyAsync(cnt, rd.counters, sizeof cnt, hipMemcpyDeviceToHost, st) != hipSuccess) return CRT_E_HIP;
+            if (hipStreamSynchronize(st) != hipSuccess) return CRT_E_HIP;
+            if (cnt[0] > P || cnt[1] > P) return CRT_E_HIP;       /* cannot happen: one push of each kind per path */
+            if (cnt[1] > 0) {
+                rc = crt_shadow_batch_dev(r->scene, rd.srays, rd.sdist, cnt[1], 0, rd.socc, st);
+                if (rc != CRT_OK) return rc;
+                if (crt_scene_last_kernel_ms(r->scene, &ms) == CRT_OK) r->stats.ms_shadow += ms;
+                r->stats.rays_shadow += cnt[1];
+                hipLaunchKernelGGL(k_pt_accumulate, dim3((cnt[1] + 255) / 256), dim3(256), 0, st, rd, cnt[1]);
+            }
+            n = cnt[0]; cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_pt_finish, dim3((rd.npix + 255) / 256), dim3(256), 0, st, rd, spp, first_sample);
+        if (hipGetLastError() != hipSuccess) return CRT_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return CRT_E_HIP;
+        r->samples += spp; done += spp;
+    }
+    r->stats.samples = r->samples;
+    r->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+
+int crt_renderer_read(crt_renderer* r, float* color_buffer, uint32_t* num_samples)
+{
+    if (!r) return CRT_E_INVALID;
+    DevGuard g(r->device);
+    if (color_buffer && hipMemcpy(color_buffer, r->rd.color, 3 * (size_t)r->rd.npix * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return CRT_E_HIP;
+    if (num_samples) *num_samples = (uint32_t)r->samples;
+    return CRT_OK;
+}
+
+int crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out)
+{
+    if (!r || !out) return CRT_E_INVALID;
+    *out = r->stats;
+    return CRT_OK;
+}
+
+} // extern "C"

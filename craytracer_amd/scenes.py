@@ -176,6 +176,72 @@ def cornell29():
     return sl.to_input()
 
 
+# cornell_box.txt:5-53 (DIFF_COLOR / COLOR / INTENSITY values; data) and the MATERIAL line of each object (:68-246)
+CORNELL_MATERIALS = [
+    ("floor", api.MAT_MATTE, (0.740064, 0.742313, 0.733934), 0.0),
+    ("ceiling", api.MAT_MATTE, (0.740064, 0.742313, 0.733934), 0.0),
+    ("backwall", api.MAT_MATTE, (0.740064, 0.742313, 0.733934), 0.0),
+    ("leftwall", api.MAT_MATTE, (0.366046, 0.0371827, 0.0416385), 0.0),
+    ("rightwall", api.MAT_MATTE, (0.162928, 0.408903, 0.0833759), 0.0),
+    ("emissive1", api.MAT_EMISSIVE, (1.0, 0.85, 0.5), 90.0),
+]
+CORNELL_RECT_MATERIALS = ["emissive1", "emissive1", "floor", "ceiling", "backwall", "rightwall", "leftwall", "floor", "ceiling"]
+CORNELL_TRI_MATERIAL = "ceiling"
+
+
+def cornell29_render(max_depth=5, seed=1, samples_in_flight=0):
+    """S1 with its materials and lights: (SceneInput, RenderDesc).  ENV_LIGHT CONSTANT WHITE, intensity 0
+    (cornell_box.txt:57-60); world_radius is irrelevant at intensity 0 and set to the box diagonal x 2."""
+    si = cornell29()
+    names = [m[0] for m in CORNELL_MATERIALS]
+    mats = np.array([api.material(m[1], m[2], m[3]) for m in CORNELL_MATERIALS], api.MATERIAL_DTYPE)
+    obj_mat = [names.index(n) for n in CORNELL_RECT_MATERIALS] + [names.index(CORNELL_TRI_MATERIAL)] * len(CORNELL_TRIS)
+    desc = api.RenderDesc(si, obj_mat, mats, max_depth, seed=seed, env=((1.0, 1.0, 1.0), 0.0, 1930.0),
+                          samples_in_flight=samples_in_flight)
+    return si, desc
+
+
+def cornell_camera(width, height, fov=0.6911, L=None):
+    """Camera of cornell_box.txt:2-3 with the reference's default focal distance; fov as config (main.cpp fov)."""
+    cam = api.make_camera(CORNELL_CAMERA[0], CORNELL_CAMERA[1], L=L)
+    return cam, api.make_film(cam, fov, width, height, L=L)
+
+
+def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intensity=0.25, samples_in_flight=0,
+                tri_type=None):
+    """A displaced blob (TRIANGLE objects) in a unit room of 12 triangles, two matte spheres, a sphere
+    light, a disk light, a rectangle light under the ceiling (slightly tilted, so its box is not flat)
+    and a constant environment light seen through nothing (the room is closed) but sampled:
+    every branch of estimateDirect.  Returns (SceneInput, RenderDesc, camera position, look point)."""
+    tri_type = api.TRIANGLE if tri_type is None else tri_type
+    blob = blob_mesh(n_lat, n_lon, seed, radius=1.0, displace=0.45) * F32(0.3) + np.tile(np.array([0.5, 0.42, 0.45], F32), 3)
+    sl = ShapeList()
+    mat_of = []
+    for tri in room_tris((0, 0, 0), (1, 1, 1)):
+        sl.triangle(tri, tri_type)
+    walls = [0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 0, 0]          # one red and one green wall pair, rest white
+    mat_of += walls
+    for tri in blob.astype(F32):
+        sl.triangle(tri, tri_type)
+    mat_of += [3] * len(blob)
+    sl.rectangle((0.35, 0.97, 0.35), (0.3, 0.02, 0.0), (0.0, 0.0, 0.3)); mat_of.append(4)
+    sl.rectangle((0.35, 0.97, 0.65), (0.3, 0.02, 0.0), (0.0, 0.0, -0.3)); mat_of.append(4)   # same place, opposite normal
+    sl.sphere((0.18, 0.12, 0.75), 0.12); mat_of.append(5)
+    sl.sphere((0.82, 0.10, 0.70), 0.10); mat_of.append(0)
+    sl.sphere((0.85, 0.80, 0.20), 0.05); mat_of.append(6)                                   # sphere light
+    sl.disk((0.02, 0.5, 0.5), _normalize32((1.0, 0.1, 0.0)), 0.15); mat_of.append(7)            # disk light on the left wall
+    mats = np.array([
+        api.material(api.MAT_MATTE, (0.74, 0.74, 0.73)), api.material(api.MAT_MATTE, (0.37, 0.04, 0.04)),
+        api.material(api.MAT_MATTE, (0.16, 0.41, 0.08)), api.material(api.MAT_MATTE, (0.55, 0.5, 0.3)),
+        api.material(api.MAT_EMISSIVE, (1.0, 0.85, 0.5), 12.0), api.material(api.MAT_MATTE, (0.2, 0.3, 0.7)),
+        api.material(api.MAT_EMISSIVE, (0.6, 0.8, 1.0), 40.0), api.material(api.MAT_EMISSIVE, (1.0, 0.4, 0.3), 6.0),
+    ], api.MATERIAL_DTYPE)
+    si = sl.to_input()
+    env = ((1.0, 1.0, 1.0), env_intensity, 3.5) if env_intensity is not None else None
+    desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=env, samples_in_flight=samples_in_flight)
+    return si, desc, (0.5, 0.5, 0.98), (0.5, 0.45, 0.0)
+
+
 def cube_tris(center, half):
     c = np.asarray(center, F32)
     h = F32(half)

@@ -248,6 +248,63 @@ int  crt_film_dimension(crt_film* film, float fov, int res_width, int res_height
 int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* film, uint32_t first_pixel, size_t n,
                           const float* d_image_samples, const float* d_lens_samples, crt_ray* d_rays, void* stream);
 
+/* ---- wavefront path tracing (restricted form) ------------------ */
+/* pathTrace (trace.h:399-532) + uniformSampleOneLight (:359-397) + estimateDirect (:221-357) +
+ * the per-pixel sample loop of threadFunc (main.cpp:88-149), turned from "one path per call" into
+ * "one bounce of every path per kernel": generate -> { extend (crt_intersect_batch_dev) -> shade ->
+ * shadow (crt_shadow_batch_dev) -> accumulate } x (max_depth + 1) -> add to the colour buffer.
+ * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
+ *   geometry  TRIANGLE, FLAT_TRIANGLE, RECTANGLE, SPHERE; DISK only with an EMISSIVE material;
+ *   materials MATTE with sigma == 0 and no texture (Lambertian, materials.cpp:116-128), EMISSIVE;
+ *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
+ *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform).
+ * Random numbers: the reference draws from per-thread sample tables (Sampler_getSample) and from libc
+ * rand() (trace.h:371,:516), both dependent on thread scheduling.  Here every number is
+ * crt_rng(seed, pixel, sample, dimension) (definition in DESIGN.md "N1"), so an image is a pure
+ * function of (scene, camera, seed, sample range).  Images therefore agree with the reference's in
+ * distribution, not sample for sample. */
+enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_EMISSIVE = 8 };     /* MatType, materials.h:8-18 */
+/* MATTE: color = Matte.color (materials.h Matte_s), intensity unused.  EMISSIVE: Emissive.color, .intensity. */
+typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; } crt_material;
+
+typedef struct crt_render_desc {
+    const crt_scene_input* objects;      /* the insertion-order arrays the scene was built from */
+    const int32_t*      obj_material;    /* [num_obj] index into materials[] (getObjectMatPtr, shapes.cpp) */
+    const crt_material* materials;
+    int32_t             num_materials;
+    int32_t             has_env_light;   /* sl->env_light != NULL (lights.h EnvLight, type CONSTANT) */
+    float               env_color[3];
+    float               env_intensity;
+    float               env_world_radius;/* EnvLight.world_radius as buildscene.h:836-872 computed it */
+    int32_t             max_depth;       /* params.max_depth (config.txt) */
+    uint32_t            samples_in_flight;/* samples per pixel traced concurrently; 0 = library picks (~2^22 paths) */
+    uint64_t            seed;
+} crt_render_desc;
+
+typedef struct crt_render_stats {
+    uint64_t samples;                    /* samples per pixel accumulated so far */
+    uint64_t rays_closest, rays_shadow;  /* rays handed to crt_intersect_batch_dev / crt_shadow_batch_dev */
+    double   ms_total;                   /* wall time spent inside crt_renderer_render */
+    double   ms_extend, ms_shadow;       /* traversal-kernel time of the two query kinds (HIP events) */
+} crt_render_stats;
+
+typedef struct crt_renderer crt_renderer;            /* opaque; owns device memory on the scene's GPU */
+
+/* GPU the scene lives on. */
+int  crt_scene_device(const crt_scene* s, int* device);
+/* The scene must have been built from desc->objects (hit ids index obj_material).  The renderer
+ * keeps a pointer to `scene` (destroy the renderer first); nothing else host-side is retained. */
+int  crt_renderer_create(crt_scene* scene, const crt_render_desc* desc, const crt_camera* cam, const crt_film* film,
+                         crt_renderer** out);
+void crt_renderer_destroy(crt_renderer* r);
+/* Adds `num_samples` samples per pixel (sample indices continue from the previous call) to the
+ * colour buffer; the loop `for p < params.num_samples` of main.cpp:295.  Returns when done. */
+int  crt_renderer_render(crt_renderer* r, uint32_t num_samples);
+/* color_buffer: [height*width*3] floats, the running SUM of per-sample radiance exactly as
+ * main.cpp:139-141 keeps it (divide by *num_samples for the image, util.h genImageFromColorBuffer). */
+int  crt_renderer_read(crt_renderer* r, float* color_buffer, uint32_t* num_samples);
+int  crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out);
+
 /* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)
  * and g_intersect_count (shapes.cpp:3).  Counting is off by default (it costs atomics);
  * when on, kernels add per-ray node / primitive-test counts. */

@@ -62,6 +62,13 @@ void oracle_film_dimension(crt_film* f, float fov, int w, int h, const crt_camer
 void oracle_primary_rays(const crt_camera* c, const crt_film* f, unsigned first_pixel, size_t n,
                          const float* image_samples, const float* lens_samples, crt_ray* rays);
 
+/* path tracing, restricted form (crt_oracle_trace.cpp; checker for crt_renderer_*).  color_buffer
+ * [npix*3] is added to (main.cpp:139-141); samples first_sample .. first_sample + num_samples - 1.
+ * Returns 0, or -1 for a scene outside the restricted form. */
+float oracle_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
+int   oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt_camera* cam, const crt_film* film,
+                    uint32_t first_sample, uint32_t num_samples, float* color_buffer, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

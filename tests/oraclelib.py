@@ -70,6 +70,10 @@ def _load_oracle(path):
         L.oracle_film_dimension.restype = None
         L.oracle_primary_rays.argtypes = [C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm), C.c_uint, C.c_size_t, vp, vp, vp]
         L.oracle_primary_rays.restype = None
+        L.oracle_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_rng.restype = C.c_float
+        L.oracle_render.argtypes = [vp, C.POINTER(api.CrtRenderDesc), C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm),
+                                    C.c_uint32, C.c_uint32, vp, C.c_int]
     return L
 
 
@@ -178,6 +182,16 @@ class OracleScene(_SceneBase):
         if counters:
             return t, occ.astype(bool), {"nodes_visited": c.nodes_visited, "prims_tested": c.prims_tested}
         return t, occ.astype(bool)
+
+    def render(self, desc, cam, flm, first_sample, num_samples, color_buffer=None, nthreads=8):
+        """oracle_render: adds samples [first_sample, first_sample + num_samples) to color_buffer [h, w, 3]."""
+        if color_buffer is None:
+            color_buffer = np.zeros((flm.frame_res_height, flm.frame_res_width, 3), np.float32)
+        assert color_buffer.dtype == np.float32 and color_buffer.flags.c_contiguous
+        rc = self.L.oracle_render(self.h, C.byref(desc.c), C.byref(cam), C.byref(flm), int(first_sample), int(num_samples),
+                                  color_buffer.ctypes.data, int(nthreads))
+        assert rc == 0, "oracle_render: scene outside the restricted form"
+        return color_buffer
 
     def intersect_object(self, index, ray):
         ray = np.ascontiguousarray(ray, np.float32)

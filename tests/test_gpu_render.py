@@ -1,0 +1,129 @@
+"""crt_renderer_* (wavefront path tracing, SURVEY 8f N1 restricted form) on the GPU against
+oracle_render, the CPU restatement of pathTrace / estimateDirect (PARITY UNPINNED for trace.h's
+control flow, see oracle/crt_oracle_trace.cpp), with the same counter-based random numbers.
+
+The bar is bit-identical images.  Both sides do the same float32 / float64 operations in the same
+order (no contraction), sqrt and divide round correctly on both, and the one libm call on the path,
+cosf / sinf in the sampling maps, is glibc's algorithm restated for the device (crt_libm.h, checked
+against the platform libm on every float by test_libm.py).  Nothing weaker would hold: the reference
+offsets no ray, so one different last bit in a hit point flips a self-shadowing decision and changes
+the pixel visibly (with the device's own cosf / sinf, 27 % of the pixels of the first test differ).
+"""
+import numpy as np
+import pytest
+
+from craytracer_amd import api, scenes
+import oraclelib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(si, desc, cam, flm, accel, passes):
+    built = api.BuiltScene(si, accel)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, desc, cam, flm)
+    for n in passes:
+        r.render(n)
+    buf, ns = r.read()
+    st = r.stats()
+    r.close()
+    scene.close()
+    built.close()
+    return buf, ns, st
+
+
+def compare(got, want):
+    assert np.isfinite(got).all() and got.max() > 0
+    assert ol.same_bits(got, want), "%.5f of the pixels are bit-identical" % (got == want).all(axis=2).mean()
+
+
+@pytest.mark.parametrize("accel", ["NONE", "BVH4", "BVH", "GRID"])
+def test_cornell_box_against_the_oracle(accel):
+    """S1 with its materials (cornell_box.txt), 96 x 96, 8 samples, depth 5.  Through the accelerators the
+    flat rectangles are partly missed, by the reference too (test_gpu_configs); the images still agree."""
+    si, desc = scenes.cornell29_render(max_depth=5, seed=11)
+    cam, flm = scenes.cornell_camera(96, 96)
+    got, ns, st = gpu_render(si, desc, cam, flm, api.ACCEL_NAMES[accel], [8])
+    assert ns == 8 and st["samples"] == 8 and st["rays_closest"] >= 8 * 96 * 96
+    want = ol.OracleScene(si, api.ACCEL_NAMES[accel]).render(desc, cam, flm, 0, 8)
+    compare(got, want)
+    if accel == "NONE":
+        light = want[..., 0] == np.float32(8 * 90.0)                 # pixels that see the light on every sample
+        assert light.sum() > 20 and (got[light] == want[light]).all()
+
+
+def test_room_with_every_light_kind():
+    """Triangle mesh + matte spheres; rectangle, sphere and disk lights and a sampled constant
+    environment light; QBVH."""
+    si, desc, pos, look = scenes.render_room(48, 96, max_depth=6, rng_seed=5)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 128, 96)
+    got, ns, st = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [6])
+    want = ol.OracleScene(si, api.ACCEL_BVH4).render(desc, cam, flm, 0, 6)
+    compare(got, want)
+    assert st["rays_shadow"] > 0
+
+
+def test_flat_triangles_keep_their_winding_normal():
+    si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 64, 64)
+    got, _, _ = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [4])
+    want = ol.OracleScene(si, api.ACCEL_BVH4).render(desc, cam, flm, 0, 4)
+    compare(got, want)
+
+
+def test_passes_add_up_and_runs_repeat():
+    """render(3) + render(5) == render(8) bit for bit (sample indices continue), also when the
+    samples in flight differ; and a second run with the same seed repeats the first."""
+    si, desc = scenes.cornell29_render(max_depth=4, seed=3)
+    cam, flm = scenes.cornell_camera(64, 48)
+    a, na, _ = gpu_render(si, desc, cam, flm, api.ACCEL_NONE, [8])
+    b, nb, _ = gpu_render(si, desc, cam, flm, api.ACCEL_NONE, [3, 5])
+    _, desc1 = scenes.cornell29_render(max_depth=4, seed=3, samples_in_flight=1)
+    c, nc, _ = gpu_render(si, desc1, cam, flm, api.ACCEL_NONE, [8])
+    assert na == nb == nc == 8
+    assert ol.same_bits(a, b) and ol.same_bits(a, c)
+    _, desc2 = scenes.cornell29_render(max_depth=4, seed=4)
+    d, _, _ = gpu_render(si, desc2, cam, flm, api.ACCEL_NONE, [8])
+    assert not ol.same_bits(a, d)
+
+
+def test_depth_zero_is_emission_only():
+    si, desc = scenes.cornell29_render(max_depth=0, seed=1)
+    cam, flm = scenes.cornell_camera(64, 64)
+    got, _, st = gpu_render(si, desc, cam, flm, api.ACCEL_NONE, [2])
+    want = ol.OracleScene(si, api.ACCEL_NONE).render(desc, cam, flm, 0, 2)
+    assert ol.same_bits(got, want)
+    assert st["rays_shadow"] == 0 and st["rays_closest"] == 2 * 64 * 64
+    vals = np.unique(got[..., 0])
+    assert set(vals.tolist()) <= {0.0, 90.0, 180.0}
+
+
+def test_unsupported_scenes_are_refused():
+    si, desc = scenes.cornell29_render()
+    cam, flm = scenes.cornell_camera(8, 8)
+    built = api.BuiltScene(si, api.ACCEL_NONE)
+    scene = api.Scene(built)
+    mats = desc.materials.copy()
+    mats[0]["sigma"] = 0.3                                           # Oren-Nayar
+    bad = api.RenderDesc(si, desc.obj_material, mats, 3)
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(scene, bad, cam, flm)
+    assert e.value.code == -4
+    mats = desc.materials.copy()
+    mats[1]["type"] = 2                                              # MIRROR
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
+    assert e.value.code == -4
+    om = desc.obj_material.copy()
+    om[3] = 99
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(scene, api.RenderDesc(si, om, desc.materials, 3), cam, flm)
+    assert e.value.code == -1
+    s2 = scenes.analytic_scene()                                     # planes, instanced shapes
+    b2 = api.BuiltScene(s2, api.ACCEL_BVH4)
+    sc2 = api.Scene(b2)
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(sc2, api.RenderDesc(s2, np.zeros(s2.num_obj, np.int32), desc.materials, 3), cam, flm)
+    assert e.value.code == -4
