@@ -69,6 +69,15 @@ float oracle_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
 int   oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt_camera* cam, const crt_film* film,
                     uint32_t first_sample, uint32_t num_samples, float* color_buffer, int nthreads);
 
+/* pieces of the above, exposed for comparison with the reference's own code (tests/test_trace_pieces.py):
+ * ShadeRec tail (out = hit_point, normal, wo, dpdu), sampling maps, local basis, Lambertian BSDF */
+void  oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* ray, float t, float* out);
+void  oracle_trace_disk(const float* in, float* out);
+void  oracle_trace_hemisphere(const float* in, float* out);
+void  oracle_trace_local_basis(const float* a, const float* normal, float* out);
+float oracle_trace_lambertian(const float* cd, const float* basis, const float* wo, const float* sample,
+                              float* f_out, float* wi_out, float* f_eval);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,7 +142,7 @@ void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hi
     vec3_scale(disp, ray.d, hit.t);
     vec3_add(sr->hit_point, ray.o, disp);                          /* getPointOnRay */
     vec3_negate(sr->wo, ray.d);
-    sr->mat = &S.d->materials[S.d->obj_material[hit.obj]];
+    sr->mat = S.d->obj_material ? &S.d->materials[S.d->obj_material[hit.obj]] : 0;
     if (type == CRT_TRIANGLE) {
         vec3_copy(sr->normal, &S.tri_normal[3 * (size_t)ref]);
         if (vec3_dot(sr->wo, sr->normal) < 0.0f) vec3_negate(sr->normal, sr->normal);
@@ -393,6 +393,21 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
     vec3_copy(radiance, L);
 }
 
+void triangleSetup(Setup* S, const crt_scene_input* in)
+{
+    S->tri_normal.resize(3 * (size_t)in->num_tris);
+    S->tri_dpdu.resize(3 * (size_t)in->num_tris);
+    for (int k = 0; k < in->num_tris; k++) {                       /* calcTriangleNormal, triangle.cpp:4-12 */
+        const float* v = in->tri_verts + 9 * (size_t)k;
+        vec3 tmp1, tmp2, tmp3;
+        vec3_sub(tmp1, v + 3, v);
+        vec3_sub(tmp2, v + 6, v);
+        vec3_cross(tmp3, tmp1, tmp2);
+        vec3_normalize(&S->tri_normal[3 * (size_t)k], tmp3);
+        vec3_normalize(&S->tri_dpdu[3 * (size_t)k], tmp1);
+    }
+}
+
 bool vec3_hasNanOrInf(const vec3 a)
 {
     for (int k = 0; k < 3; k++) if (isnan(a[k]) || isinf(a[k])) return true;
@@ -417,17 +432,7 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
     Setup S;
     S.scene = scene; S.d = d; S.seed = d->seed;
     const crt_scene_input* in = d->objects;
-    S.tri_normal.resize(3 * (size_t)in->num_tris);
-    S.tri_dpdu.resize(3 * (size_t)in->num_tris);
-    for (int k = 0; k < in->num_tris; k++) {                       /* calcTriangleNormal, triangle.cpp:4-12 */
-        const float* v = in->tri_verts + 9 * (size_t)k;
-        vec3 tmp1, tmp2, tmp3;
-        vec3_sub(tmp1, v + 3, v);
-        vec3_sub(tmp2, v + 6, v);
-        vec3_cross(tmp3, tmp1, tmp2);
-        vec3_normalize(&S.tri_normal[3 * (size_t)k], tmp3);
-        vec3_normalize(&S.tri_dpdu[3 * (size_t)k], tmp1);
-    }
+    triangleSetup(&S, in);
     if (d->has_env_light) {
         Light l; l.kind = 0; l.obj_type = -1; l.shape = 0;
         vec3_copy(l.color, d->env_color); l.intensity = d->env_intensity;
@@ -485,6 +490,38 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
         th.emplace_back([&, k]() { for (uint32_t b = (uint32_t)k * strip; b < npix; b += strip * (uint32_t)nthreads) work(b, b + strip < npix ? b + strip : npix); });
     for (auto& t : th) t.join();
     return 0;
+}
+
+/* ---- the pieces tests/test_trace_pieces.py compares with the reference's own code (oracle/_ref) ---- */
+void oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* ray, float t, float* out)
+{
+    crt_render_desc d; memset(&d, 0, sizeof d);
+    d.objects = in;
+    Setup S; S.scene = 0; S.d = &d; S.seed = 0;
+    triangleSetup(&S, in);
+    crt_hit hit; hit.t = t; hit.obj = obj; hit.part = 0; hit.beta = hit.gamma = 0.0f;
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    fillShadeRec(S, &sr, *ray, hit);
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+}
+void oracle_trace_disk(const float* in, float* out) { mapSampleToDisk(out, in); }
+void oracle_trace_hemisphere(const float* in, float* out) { mapSampleToHemisphere(out, in); }
+void oracle_trace_local_basis(const float* a, const float* normal, float* out) { getVec3InLocalBasis(out, a, normal); }
+float oracle_trace_lambertian(const float* cd, const float* basis, const float* wo, const float* sample,
+                              float* f_out, float* wi_out, float* f_eval)
+{
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
+    vec3_copy(sr.cd, cd);
+    vec3 wi = {0.0f, 0.0f, 0.0f};
+    float pdf = BSDF_sample_f(f_out, wi, wo, sample, &sr);
+    vec3_copy(wi_out, wi);
+    vec3 cur_f;                                                    /* BSDF_f as estimateDirect uses it */
+    vec3_copy(cur_f, sr.cd);
+    vec3_scale(cur_f, cur_f, INV_PI);
+    vec3_copy(f_eval, BLACK);
+    vec3_add(f_eval, f_eval, cur_f);
+    return pdf;
 }
 
 } // extern "C"

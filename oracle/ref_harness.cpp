@@ -29,6 +29,8 @@
 #include "aabb.h"
 #include "util/math.h"
 #include "camera.h"
+#include "sampling.h"
+#include "reflection.h"
 
 #include <vector>
 #include <unordered_map>
@@ -475,4 +477,49 @@ REF_API int ref_sizes(int* shaderec, int* node4, int* node2, int* object_t)
 {
     *shaderec = (int)sizeof(ShadeRec); *node4 = (int)sizeof(BVHNode4); *node2 = (int)sizeof(BVHNode); *object_t = (int)sizeof(Object_t);
     return 0;
+}
+
+/* ---- pieces of the shading path that compile without trace.h ---------------- */
+/* ShadeRec as the reference's intersector leaves it: out = hit_point, normal, wo, dpdu (12 floats).
+ * dpdu is pre-set to a marker so that intersectors that never write it (triangle.cpp:154-204) show. */
+REF_API float ref_shade_rec(const ref_scene* s, int final_index, const crt_ray* ray, float* out, float dpdu_marker)
+{
+    Ray r; to_ray(&r, ray);
+    ShadeRec sr;
+    vec3_assign(sr.dpdu, dpdu_marker, dpdu_marker, dpdu_marker);
+    vec3_assign(sr.normal, dpdu_marker, dpdu_marker, dpdu_marker);
+    float t = rayIntersectObject(&sr, s->objects[final_index], r);
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+    return t;
+}
+REF_API void ref_map_sample_to_disk(const float* in, float* out) { vec2 i = { in[0], in[1] }; vec2 o; mapSampleToDisk(o, i); out[0] = o[0]; out[1] = o[1]; }
+REF_API void ref_map_sample_to_hemisphere(const float* in, float* out) { vec2 i = { in[0], in[1] }; vec3 o; mapSampleToHemisphere(o, i); memcpy(out, o, 12); }
+REF_API void ref_vec3_in_local_basis(const float* a, const float* normal, float* out)
+{
+    vec3 aa = { a[0], a[1], a[2] }, nn = { normal[0], normal[1], normal[2] }, r;
+    getVec3InLocalBasis(r, aa, nn);
+    memcpy(out, r, 12);
+}
+/* BSDF with one Lambertian lobe (BSDF_addLambertian): BSDF_sample_f and BSDF_f.  basis = tangent,
+ * binormal, normal (9 floats).  Returns the pdf; f_out, wi_out from BSDF_sample_f; f_eval from BSDF_f(wi_out). */
+REF_API float ref_lambertian_bsdf(const float* cd, const float* basis, const float* wo, const float* sample,
+                                  float* f_out, float* wi_out, float* f_eval)
+{
+    static bool pool = initBSDFMem(1, 4);
+    (void)pool;
+    BSDF bsdf;
+    bsdf.num_bxdf = 0;
+    memcpy(bsdf.tangent, basis, 12); memcpy(bsdf.binormal, basis + 3, 12); memcpy(bsdf.normal, basis + 6, 12);
+    vec3 c = { cd[0], cd[1], cd[2] };
+    BSDF_addLambertian(&bsdf, c);
+    vec3 f = { 0, 0, 0 }, wi = { 0, 0, 0 }, w = { wo[0], wo[1], wo[2] };
+    vec2 smp = { sample[0], sample[1] };
+    BxDFFlags flags;
+    float pdf = BSDF_sample_f(f, wi, &flags, w, smp, &bsdf);
+    memcpy(f_out, f, 12); memcpy(wi_out, wi, 12);
+    vec3 fe = { 0, 0, 0 };
+    BSDF_f(fe, wi, w, &bsdf, (BxDFFlags)(BSDF_SPECULAR | BSDF_GLOSSY));
+    memcpy(f_eval, fe, 12);
+    BSDF_freeBxDFs(&bsdf);
+    return pdf;
 }

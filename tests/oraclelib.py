@@ -74,6 +74,15 @@ def _load_oracle(path):
         L.oracle_rng.restype = C.c_float
         L.oracle_render.argtypes = [vp, C.POINTER(api.CrtRenderDesc), C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm),
                                     C.c_uint32, C.c_uint32, vp, C.c_int]
+        L.oracle_trace_shade_rec.argtypes = [C.POINTER(api.CrtSceneInput), C.c_int, vp, C.c_float, vp]
+        L.oracle_trace_shade_rec.restype = None
+        for name in ("oracle_trace_disk", "oracle_trace_hemisphere"):
+            getattr(L, name).argtypes = [vp, vp]
+            getattr(L, name).restype = None
+        L.oracle_trace_local_basis.argtypes = [vp, vp, vp]
+        L.oracle_trace_local_basis.restype = None
+        L.oracle_trace_lambertian.argtypes = [vp] * 7
+        L.oracle_trace_lambertian.restype = C.c_float
     return L
 
 
@@ -109,6 +118,15 @@ def ref():
         L.ref_film_dimension.restype = None
         L.ref_primary_rays.argtypes = [C.POINTER(api.CrtCamera), C.POINTER(api.CrtFilm), C.c_uint, C.c_size_t, vp, vp, vp]
         L.ref_primary_rays.restype = None
+        L.ref_shade_rec.argtypes = [vp, C.c_int, vp, vp, C.c_float]
+        L.ref_shade_rec.restype = C.c_float
+        for name in ("ref_map_sample_to_disk", "ref_map_sample_to_hemisphere"):
+            getattr(L, name).argtypes = [vp, vp]
+            getattr(L, name).restype = None
+        L.ref_vec3_in_local_basis.argtypes = [vp, vp, vp]
+        L.ref_vec3_in_local_basis.restype = None
+        L.ref_lambertian_bsdf.argtypes = [vp] * 7
+        L.ref_lambertian_bsdf.restype = C.c_float
         _ref = L
     return _ref
 

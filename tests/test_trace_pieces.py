@@ -1,0 +1,92 @@
+"""Pieces of the shading path that DO compile from the reference's sources (oracle/_ref): the ShadeRec
+an intersector leaves behind, the sampling maps, getVec3InLocalBasis, and the one-lobe Lambertian BSDF
+(BSDF_addLambertian + BSDF_sample_f + BSDF_f, reflection.cpp).  The restatement in
+oracle/crt_oracle_trace.cpp must give the same bits.  (pathTrace / estimateDirect themselves live in
+trace.h, which needs GLFW: not covered here, "parity unpinned".)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from craytracer_amd import api, scenes
+import oraclelib as ol
+
+pytestmark = pytest.mark.ref
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def test_shade_rec_of_triangle_rectangle_sphere():
+    si, desc, pos, look = scenes.render_room(6, 12)
+    rs = ol.RefScene(si, api.ACCEL_NONE)
+    order, _ = rs.order()
+    final_of = {int(i): k for k, i in enumerate(order)}
+    cin = si.c_struct()
+    rng = np.random.default_rng(4)
+    rays = np.zeros((6000, 6), np.float32)
+    rays[:, :3] = rng.random((6000, 3), dtype=np.float32) * 0.9 + 0.05
+    d = rng.standard_normal((6000, 3)).astype(np.float32)
+    rays[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    hits = rs.intersect(rays)
+    seen = {}
+    marker = np.float32(-123.25)
+    L, R = ol.oracle(), ol.ref()
+    for ray, h in zip(rays, hits):
+        obj = int(h["obj"])
+        if obj < 0:
+            continue
+        typ = int(si.obj_type[obj])
+        if typ == api.DISK:                                    # emissive only in this form; its ShadeRec is never read
+            continue
+        want = np.zeros(12, np.float32)
+        t = R.ref_shade_rec(rs.h, final_of[obj], _p(ray), _p(want), marker)
+        assert np.float32(t) == h["t"]
+        got = np.zeros(12, np.float32)
+        L.oracle_trace_shade_rec(C.byref(cin), obj, _p(ray), h["t"], _p(got))
+        assert ol.same_bits(got[:9], want[:9]), (typ, got, want)
+        if typ == api.TRIANGLE:
+            assert (want[9:] == marker).all()                 # triangle.cpp:154-168 never writes dpdu
+        else:
+            assert ol.same_bits(got[9:], want[9:]), (typ, got, want)
+        seen[typ] = seen.get(typ, 0) + 1
+    assert seen.get(api.TRIANGLE, 0) > 1000 and seen.get(api.RECTANGLE, 0) > 20 and seen.get(api.SPHERE, 0) > 50
+
+
+def test_sampling_maps_and_local_basis():
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(5)
+    smp = rng.random((20000, 2), dtype=np.float32)
+    smp[:8] = [[0, 0], [0, 1], [0.25, 1], [0.5, 1], [0.75, 1], [0.999999, 1], [0.5, 0], [0.125, 0.5]]
+    nrm = rng.standard_normal((20000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    a2, b2, a3, b3, a4, b4 = (np.zeros(k, np.float32) for k in (2, 2, 3, 3, 3, 3))
+    for s, n in zip(smp, nrm):
+        L.oracle_trace_disk(_p(s), _p(a2)); R.ref_map_sample_to_disk(_p(s), _p(b2))
+        L.oracle_trace_hemisphere(_p(s), _p(a3)); R.ref_map_sample_to_hemisphere(_p(s), _p(b3))
+        assert ol.same_bits(a2, b2) and ol.same_bits(a3, b3)
+        L.oracle_trace_local_basis(_p(a3), _p(n), _p(a4)); R.ref_vec3_in_local_basis(_p(b3), _p(n), _p(b4))
+        assert ol.same_bits(a4, b4)
+
+
+def test_lambertian_bsdf():
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(6)
+    for k in range(5000):
+        n = rng.standard_normal(3).astype(np.float32); n /= np.linalg.norm(n)
+        t = np.cross(n, rng.standard_normal(3)).astype(np.float32); t /= np.linalg.norm(t)
+        b = np.cross(n, t).astype(np.float32)
+        basis = np.concatenate([t, b, n]).astype(np.float32)
+        wo = rng.standard_normal(3).astype(np.float32); wo /= np.linalg.norm(wo)
+        if k % 50 == 0:
+            wo = t.copy()                                      # grazing: wo_local.z == 0 up to rounding
+        cd = rng.random(3, dtype=np.float32)
+        smp = rng.random(2, dtype=np.float32)
+        fa, wa, ea, fb, wb, eb = (np.zeros(3, np.float32) for _ in range(6))
+        pa = L.oracle_trace_lambertian(_p(cd), _p(basis), _p(wo), _p(smp), _p(fa), _p(wa), _p(ea))
+        pb = R.ref_lambertian_bsdf(_p(cd), _p(basis), _p(wo), _p(smp), _p(fb), _p(wb), _p(eb))
+        assert np.float32(pa) == np.float32(pb)
+        if pb != 0.0:
+            assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
+        assert ol.same_bits(ea, eb)
