@@ -361,6 +361,27 @@ def courtyard(n_copies, n_lat, n_lon, seed=5, room=10.0):
     return api.SceneInput(np.concatenate(parts, 0))
 
 
+def courtyard_render(n_copies, n_lat, n_lon, seed=5, room=10.0, max_depth=5, rng_seed=1, env_intensity=1.0,
+                     samples_in_flight=0):
+    """The courtyard() stand-in as a render scene: TRIANGLE objects, open to the sky (the two ceiling
+    triangles removed), lit by a constant environment light -- "incoherent diffuse bounces" of
+    BASELINE.json's last config.  White walls, four blob colours.  Returns (SceneInput, RenderDesc,
+    camera position, look point)."""
+    si0 = courtyard(n_copies, n_lat, n_lon, seed, room)
+    tris = np.delete(si0.tri_verts, [6, 7], axis=0)                 # y = +h face of room_tris
+    n = len(tris)
+    si = api.SceneInput(tris, None, np.full(n, api.TRIANGLE, np.int32), np.arange(n, dtype=np.int32))
+    per_copy = 2 * n_lat * n_lon
+    mat_of = np.zeros(n, np.int32)
+    mat_of[10:] = 1 + (np.arange(n - 10) // per_copy) % 4
+    mats = np.array([api.material(api.MAT_MATTE, (0.74, 0.74, 0.73)), api.material(api.MAT_MATTE, (0.6, 0.3, 0.2)),
+                     api.material(api.MAT_MATTE, (0.3, 0.55, 0.25)), api.material(api.MAT_MATTE, (0.25, 0.35, 0.6)),
+                     api.material(api.MAT_MATTE, (0.7, 0.65, 0.4))], api.MATERIAL_DTYPE)
+    desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=((1.0, 1.0, 1.0), env_intensity, 4.0 * room),
+                          samples_in_flight=samples_in_flight)
+    return si, desc, (room * 0.5, room * 0.3, room * 0.97), (room * 0.5, room * 0.2, 0.0)
+
+
 def buddha_like(n_lat=512, n_lon=1024, seed=3):
     """S3-style stand-in for the ~1M-triangle Buddha: one finely displaced blob in a room."""
     blob = blob_mesh(n_lat, n_lon, seed, radius=1.0, displace=0.45) * F32(0.4) + np.tile(np.array([0.5, 0.5, 0.5], F32), 3)
