@@ -128,6 +128,63 @@ def gen_shadow_rays(sc, si, d_rays, seed, device):
     return rays, ld.float().contiguous()
 
 
+def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, barrier, n_copies, n_lat, n_lon):
+    import torch.distributed as dist
+    width, height, depth, spp = 3840, 2160, 5, args.render_spp
+    si, desc, pos, look = scenes.courtyard_render(n_copies, n_lat, n_lon, seed=5, max_depth=depth, rng_seed=1)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, local_rank)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.0, width, height)
+    r = api.Renderer(sc, desc, cam, flm)
+    d_img = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    r.render(1)                                           # warm-up pass
+    r.reset(rank * spp)                                   # rank k renders samples [k*spp, (k+1)*spp) of the one image
+    s0 = r.stats()
+    barrier()
+    t0 = time.perf_counter()
+    r.render(spp)
+    r.read_dev(d_img.data_ptr(), stream)
+    if world > 1:
+        dist.all_reduce(d_img)                            # RCCL: sum of the ranks' colour buffers
+    barrier()
+    dt = shard.max_over_ranks(time.perf_counter() - t0, device)
+    s1 = r.stats()
+    rays = (s1["rays_closest"] - s0["rays_closest"]) + (s1["rays_shadow"] - s0["rays_shadow"])
+    mean = float(d_img.mean().item()) / (spp * world)
+    res = {"metric": "samples/sec/pixel, wavefront path tracing (matte + env light), QBVH", "value": round(spp * world / dt, 3),
+           "unit": "samples/s/pixel", "workload": "courtyard opened to a constant sky, %d triangles, %dx%d, max depth %d, %d spp per GPU timed"
+           % (si.num_obj, width, height, depth, spp), "seconds": round(dt, 4),
+           "mrays_per_s_all_queries_per_gpu": round(rays / (s1["ms_total"] - s0["ms_total"]) / 1e3, 1),
+           "traversal_kernel_fraction": round(((s1["ms_extend"] - s0["ms_extend"]) + (s1["ms_shadow"] - s0["ms_shadow"]))
+                                              / (s1["ms_total"] - s0["ms_total"]), 3),
+           "rays_per_sample_per_pixel": round(rays / spp / (width * height), 3), "mean_radiance": round(mean, 5),
+           "reduce": "RCCL all_reduce of the colour buffers" if world > 1 else "none (1 GPU)"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oraclelib as ol
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        w2, h2 = 256, 144
+        flm2 = api.make_film(cam, 1.0, w2, h2)
+        o = ol.OracleScene(si, built=built)
+        t1 = time.perf_counter()
+        want = o.render(desc, cam, flm2, 0, 2, nthreads=cores)
+        cpu_s = time.perf_counter() - t1
+        r2 = api.Renderer(sc, desc, cam, flm2)
+        r2.render(2)
+        got, _ = r2.read()
+        r2.close()
+        res["cpu_baseline"] = {"value": round(2 * w2 * h2 / cpu_s / (width * height), 5), "unit": "samples/s/pixel at %dx%d" % (width, height),
+                               "cores": cores, "kind": "port", "sample": "%dx%d image, 2 spp, oracle_render, %.1f s" % (w2, h2, cpu_s),
+                               "gpu_image_bit_identical_on_sample": bool((got == want).all())}
+        o.close()
+    r.close()
+    sc.close()
+    built.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +198,8 @@ def main():
                     help="the library's ray binning step (inside the timed region); off = arrival order")
     ap.add_argument("--accel", default="bvh4", choices=["bvh4", "bvh", "grid"],
                     help="bvh4 = the headline QBVH path; bvh / grid = the reference's other accelerators (extra lines)")
+    ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
+    ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
     args = ap.parse_args()
@@ -232,6 +291,8 @@ def main():
         hit_frac = float((d_hits[:, 1] >= 0).float().mean().item())
         checksum = int(d_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF  # same scene + rays => same number
 
+    gpu_hits_host = None if shadow else d_hits.cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
+    host_rays_keep = d_rays.cpu().numpy()
     total_rays = float(n) * world * args.steps
     value = total_rays / elapsed / 1e6
     avg_kernel_ms = float(np.mean(kernel_ms))
@@ -294,13 +355,25 @@ def main():
                           "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
         del s_rays, s_ld, s_t, s_occ
 
+    if not shadow and args.accel == "bvh4" and not args.no_render:
+        # second half of BASELINE.json's metric: samples/sec/pixel of the wavefront path tracer on
+        # the same courtyard opened to a constant sky, 4K, depth 5.  Sample passes are sharded over the ranks
+        # (each renders its own sample range of the full frame); the colour buffers are summed over RCCL
+        # inside the timed region.
+        try:
+            del d_rays, d_hits
+            out["render"] = render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, barrier,
+                                       n_copies, n_lat, n_lon)
+        except Exception as e:  # the headline line must not depend on this leg
+            out["render"] = {"error": repr(e)[:300]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU checker timed as "the reference's path on the host cores": same tree, same rays
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as ol
         o = ol.OracleScene(si, accel, built=built)
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        host_rays = d_rays.cpu().numpy()
+        host_rays = host_rays_keep
         host_ld = d_ld.cpu().numpy() if shadow else None
 
         def cpu(lo_, hi_, threads):
@@ -332,8 +405,7 @@ def main():
             same = bool(ol.same_bits(d_t[:m].cpu().numpy(), ref[0])) and \
                 bool(np.array_equal(d_occ[:m].cpu().numpy().astype(bool), ref[1]))
         else:
-            gpu_hits = d_hits[:m].cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
-            same = bool(ol.same_bits(gpu_hits, ref))
+            same = bool(ol.same_bits(gpu_hits_host[:m], ref))
         out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                "sample": "first %d rays of the GPU batch, oracle in the reference's control flow, %.1f s" % (m, cpu_s),
                                "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4), "one_thread_O0_mrays": o0_mrays,

@@ -117,7 +117,7 @@ EXPORTS = [
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
-    "crt_renderer_get_stats",
+    "crt_renderer_get_stats", "crt_renderer_read_dev", "crt_renderer_reset",
 ]
 
 _lib = None
@@ -178,6 +178,8 @@ def lib():
     L.crt_renderer_render.argtypes = [vp, C.c_uint32]
     L.crt_renderer_read.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
     L.crt_renderer_get_stats.argtypes = [vp, C.POINTER(CrtRenderStats)]
+    L.crt_renderer_read_dev.argtypes = [vp, vp, vp]
+    L.crt_renderer_reset.argtypes = [vp, C.c_uint32]
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_strerror.restype = C.c_char_p
     L.crt_last_hip_error.argtypes = []
@@ -346,6 +348,14 @@ class Renderer:
         n = C.c_uint32()
         _check(lib().crt_renderer_read(self._h, buf.ctypes.data, C.byref(n)), "crt_renderer_read")
         return buf, n.value
+
+    def reset(self, next_sample=0):
+        """Clear the colour buffer; the next render() starts at sample index next_sample."""
+        _check(lib().crt_renderer_reset(self._h, int(next_sample)), "crt_renderer_reset")
+
+    def read_dev(self, d_color_buffer, stream=None):
+        """Copy the colour buffer into device memory at d_color_buffer ([h*w*3] floats) on `stream`."""
+        _check(lib().crt_renderer_read_dev(self._h, d_color_buffer, stream), "crt_renderer_read_dev")
 
     def stats(self):
         st = CrtRenderStats()

@@ -119,17 +119,30 @@ struct RenderDev {
     float* color;                         /* [npix*3] running sum, main.cpp:139-141 */
 };
 
-/* one atomic per wave: returns this lane's slot when `want`, any value otherwise; all 64 lanes must call */
-__device__ __forceinline__ unsigned queue_push(unsigned* counter, bool want)
+/* Queue append for a 256-thread block: ONE atomic per block for both queues (the two counters are
+ * the halves of one 64-bit word; neither half can carry, a queue holds < 2^31 entries).  Same-address
+ * atomics serialise in the L2, and one per wave per queue was what the shading kernel spent most of
+ * its time on.  All threads of the block must call; returns the slots through next_slot / shadow_slot. */
+__device__ __forceinline__ void queue_push2(unsigned long long* counters, bool want_next, bool want_shadow,
+                                            unsigned* next_slot, unsigned* shadow_slot)
 {
-    const unsigned long long m = __ballot(want);
-    if (m == 0) return 0;
-    const unsigned lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-    base = __shfl(base, leader);
-    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    __shared__ unsigned s_cnt[2][4];
+    __shared__ unsigned long long s_base;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mn = __ballot(want_next), ms = __ballot(want_shadow);
+    if (lane == 0) { s_cnt[0][wave] = (unsigned)__popcll(mn); s_cnt[1][wave] = (unsigned)__popcll(ms); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tn = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+        const unsigned ts = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+        s_base = (tn | ts) ? atomicAdd(counters, (unsigned long long)tn | ((unsigned long long)ts << 32)) : 0ull;
+    }
+    __syncthreads();
+    unsigned bn = (unsigned)s_base, bs = (unsigned)(s_base >> 32);
+    for (unsigned w = 0; w < wave; w++) { bn += s_cnt[0][w]; bs += s_cnt[1][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    *next_slot = bn + (unsigned)__popcll(mn & below);
+    *shadow_slot = bs + (unsigned)__popcll(ms & below);
 }
 
 /* threadFunc's per-pixel head, main.cpp:102-115: two Sampler_getSample values, calcImageCoord, calcCameraRay */
@@ -326,12 +339,12 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
         rd.L[3 * (size_t)p] = L.x; rd.L[3 * (size_t)p + 1] = L.y; rd.L[3 * (size_t)p + 2] = L.z;
         rd.good[p] = good;
     }
-    const unsigned ss = queue_push(rd.counters + 1, push_shadow);
+    unsigned ns, ss;
+    queue_push2((unsigned long long*)rd.counters, push_next, push_shadow, &ns, &ss);
     if (push_shadow) {
         rd.srays[ss] = sray; rd.sdist[ss] = sdist; rd.spath[ss] = p;
         rd.scontrib[3 * (size_t)ss] = scontrib.x; rd.scontrib[3 * (size_t)ss + 1] = scontrib.y; rd.scontrib[3 * (size_t)ss + 2] = scontrib.z;
     }
-    const unsigned ns = queue_push(rd.counters + 0, push_next);
     if (push_next) { rd.rays[cur ^ 1][ns] = nray; rd.qpath[cur ^ 1][ns] = p; }
 }
 
@@ -605,6 +618,26 @@ int crt_renderer_read(crt_renderer* r, float* color_buffer, uint32_t* num_sample
     DevGuard g(r->device);
     if (color_buffer && hipMemcpy(color_buffer, r->rd.color, 3 * (size_t)r->rd.npix * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return CRT_E_HIP;
     if (num_samples) *num_samples = (uint32_t)r->samples;
+    return CRT_OK;
+}
+
+int crt_renderer_reset(crt_renderer* r, uint32_t next_sample)
+{
+    if (!r) return CRT_E_INVALID;
+    DevGuard g(r->device);
+    if (hipMemsetAsync(r->rd.color, 0, 3 * (size_t)r->rd.npix * sizeof(float), r->stream) != hipSuccess) return CRT_E_HIP;
+    if (hipStreamSynchronize(r->stream) != hipSuccess) return CRT_E_HIP;
+    r->samples = next_sample;
+    r->stats.samples = next_sample;
+    return CRT_OK;
+}
+
+int crt_renderer_read_dev(crt_renderer* r, float* d_color_buffer, void* stream)
+{
+    if (!r || !d_color_buffer) return CRT_E_INVALID;
+    DevGuard g(r->device);
+    if (hipMemcpyAsync(d_color_buffer, r->rd.color, 3 * (size_t)r->rd.npix * sizeof(float), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess) return CRT_E_HIP;
     return CRT_OK;
 }
 

@@ -303,6 +303,13 @@ int  crt_renderer_render(crt_renderer* r, uint32_t num_samples);
 /* color_buffer: [height*width*3] floats, the running SUM of per-sample radiance exactly as
  * main.cpp:139-141 keeps it (divide by *num_samples for the image, util.h genImageFromColorBuffer). */
 int  crt_renderer_read(crt_renderer* r, float* color_buffer, uint32_t* num_samples);
+/* Clears the colour buffer and sets the index of the next sample: GPU k of N renders the sample range
+ * [k*S, (k+1)*S) of the same image, and the N buffers are summed (the reference's unit of work is the
+ * sample pass, main.cpp:295; its image-state file plays this role between runs, imagestate.h). */
+int  crt_renderer_reset(crt_renderer* r, uint32_t next_sample);
+/* Same buffer copied to DEVICE memory of the renderer's GPU, enqueued on `stream` (all earlier
+ * crt_renderer_render calls have completed): for reducing the buffers of several GPUs over RCCL. */
+int  crt_renderer_read_dev(crt_renderer* r, float* d_color_buffer, void* stream);
 int  crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out);
 
 /* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)

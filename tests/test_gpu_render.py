@@ -89,6 +89,36 @@ def test_passes_add_up_and_runs_repeat():
     assert not ol.same_bits(a, d)
 
 
+def test_sample_ranges_rendered_apart_add_up():
+    """What two GPUs would do: samples [0, 4) and [4, 8) rendered separately (crt_renderer_reset) and
+    summed equal one 8-sample render up to the order of the additions; each half is bit-identical
+    to the oracle's same range."""
+    si, desc = scenes.cornell29_render(max_depth=4, seed=6)
+    cam, flm = scenes.cornell_camera(64, 48)
+    built = api.BuiltScene(si, api.ACCEL_NONE)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, desc, cam, flm)
+    r.render(8)
+    whole, _ = r.read()
+    r.reset(0)
+    r.render(4)
+    lo, n_lo = r.read()
+    r.reset(4)
+    r.render(4)
+    hi, n_hi = r.read()
+    import torch
+    d = torch.zeros(48 * 64 * 3, dtype=torch.float32, device="cuda")
+    r.read_dev(d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ol.same_bits(d.cpu().numpy().reshape(48, 64, 3), hi)
+    r.close()
+    assert n_lo == 4 and n_hi == 8
+    osc = ol.OracleScene(si, api.ACCEL_NONE)
+    assert ol.same_bits(lo, osc.render(desc, cam, flm, 0, 4))
+    assert ol.same_bits(hi, osc.render(desc, cam, flm, 4, 4))
+    assert np.allclose(lo + hi, whole, rtol=1e-5, atol=1e-6)
+
+
 def test_depth_zero_is_emission_only():
     si, desc = scenes.cornell29_render(max_depth=0, seed=1)
     cam, flm = scenes.cornell_camera(64, 64)

@@ -1,5 +1,5 @@
 """samples/sec/pixel of the wavefront path tracer (crt_renderer_*) on the courtyard stand-in, QBVH.
-    python tools/bench_render.py [--copies 20 --lat 512 --lon 512] [--width 3840 --height 2160] [--spp 4] [--depth 5]
+    python tools/bench_render.py [--copies 640 --lat 64 --lon 128] [--width 3840 --height 2160] [--spp 4] [--depth 5]
 Prints one JSON line; --check N compares the first N samples of a 256 x 144 image with the CPU oracle."""
 import argparse
 import json
@@ -15,9 +15,9 @@ from craytracer_amd import api, scenes                # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--copies", type=int, default=20)
-    ap.add_argument("--lat", type=int, default=512)
-    ap.add_argument("--lon", type=int, default=512)
+    ap.add_argument("--copies", type=int, default=640)       # bench.py's courtyard-10M
+    ap.add_argument("--lat", type=int, default=64)
+    ap.add_argument("--lon", type=int, default=128)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=4)
