@@ -118,6 +118,7 @@ EXPORTS = [
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
     "crt_renderer_get_stats", "crt_renderer_read_dev", "crt_renderer_reset",
+    "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
 ]
 
 _lib = None
@@ -180,6 +181,12 @@ def lib():
     L.crt_renderer_get_stats.argtypes = [vp, C.POINTER(CrtRenderStats)]
     L.crt_renderer_read_dev.argtypes = [vp, vp, vp]
     L.crt_renderer_reset.argtypes = [vp, C.c_uint32]
+    L.crt_image_state_save.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int]
+    L.crt_image_state_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.crt_image_state_free.argtypes = [vp]
+    L.crt_image_state_free.restype = None
+    L.crt_image_from_color_buffer.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.crt_ppm_write.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_strerror.restype = C.c_char_p
     L.crt_last_hip_error.argtypes = []
@@ -372,6 +379,39 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def image_state_save(path, color_buffer, num_samples):
+    """saveImageState: color_buffer [h, w, 3] float32 sums."""
+    cb = np.ascontiguousarray(color_buffer, np.float32)
+    _check(lib().crt_image_state_save(os.fsencode(path), cb.ctypes.data, int(num_samples), cb.shape[1], cb.shape[0]),
+           "crt_image_state_save")
+
+
+def image_state_load(path):
+    """readImageState -> (color_buffer [h, w, 3], num_samples)."""
+    p, ns, w, h = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+    _check(lib().crt_image_state_load(os.fsencode(path), C.byref(p), C.byref(ns), C.byref(w), C.byref(h)), "crt_image_state_load")
+    try:
+        buf = np.ctypeslib.as_array((C.c_float * (w.value * h.value * 3)).from_address(p.value)).copy() if w.value * h.value \
+            else np.zeros(0, np.float32)
+    finally:
+        lib().crt_image_state_free(p)
+    return buf.reshape(h.value, w.value, 3), ns.value
+
+
+def image_from_color_buffer(color_buffer, num_samples):
+    """genImageFromColorBuffer + toneMap -> uint8 [h, w, 3]."""
+    cb = np.ascontiguousarray(color_buffer, np.float32)
+    img = np.zeros(cb.shape, np.uint8)
+    _check(lib().crt_image_from_color_buffer(img.ctypes.data, cb.ctypes.data, cb.size // 3, int(num_samples)),
+           "crt_image_from_color_buffer")
+    return img
+
+
+def ppm_write(path, image):
+    img = np.ascontiguousarray(image, np.uint8)
+    _check(lib().crt_ppm_write(os.fsencode(path), img.ctypes.data, img.shape[1], img.shape[0]), "crt_ppm_write")
 
 
 def _view(ptr, n, dtype):

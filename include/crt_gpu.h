@@ -312,6 +312,19 @@ int  crt_renderer_reset(crt_renderer* r, uint32_t next_sample);
 int  crt_renderer_read_dev(crt_renderer* r, float* d_color_buffer, void* stream);
 int  crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out);
 
+/* ---- image state and 8-bit output, host side ---------------------- */
+/* saveImageState / readImageState (imagestate.h:5-43): "<num_samples>\n<width> <height>\n" followed by
+ * width*height*3 raw float32 sums -- the file the reference resumes from (main.cpp:238-253) and the
+ * operand of the multi-GPU sum.  Files are interchangeable with the reference's.  load allocates
+ * *color_buffer (release with crt_image_state_free). */
+int  crt_image_state_save(const char* file_name, const float* color_buffer, int num_samples, int width, int height);
+int  crt_image_state_load(const char* file_name, float** color_buffer, int* num_samples, int* width, int* height);
+void crt_image_state_free(float* color_buffer);
+/* genImageFromColorBuffer (util/util.cpp:28-45) with toneMap (shading.h:33-49): image[3*num_pixels]. */
+int  crt_image_from_color_buffer(unsigned char* image, const float* color_buffer, int num_pixels, int num_samples);
+/* PPM_write (imagefile.h:36-57): binary P6. */
+int  crt_ppm_write(const char* file_name, const unsigned char* image, int width, int height);
+
 /* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)
  * and g_intersect_count (shapes.cpp:3).  Counting is off by default (it costs atomics);
  * when on, kernels add per-ray node / primitive-test counts. */

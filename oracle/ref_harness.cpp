@@ -31,6 +31,8 @@
 #include "camera.h"
 #include "sampling.h"
 #include "reflection.h"
+#include "util/util.h"
+#include "imagestate.h"
 
 #include <vector>
 #include <unordered_map>
@@ -522,4 +524,17 @@ REF_API float ref_lambertian_bsdf(const float* cd, const float* basis, const flo
     memcpy(f_eval, fe, 12);
     BSDF_freeBxDFs(&bsdf);
     return pdf;
+}
+
+/* ---- image state: the reference's own imagestate.h ------------------------- */
+REF_API int ref_save_image_state(float* color_buffer, int num_samples, int width, int height, const char* file_name)
+{
+    return saveImageState(color_buffer, num_samples, width, height, file_name);
+}
+REF_API int ref_read_image_state(float* out, int capacity, int* num_samples, int* width, int* height, const char* file_name)
+{
+    float* buf = 0; int size = 0;
+    readImageState(&buf, num_samples, &size, width, height, file_name);
+    if (buf) { memcpy(out, buf, sizeof(float) * (size < capacity ? size : capacity)); free(buf); }
+    return size;
 }
