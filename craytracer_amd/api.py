@@ -89,7 +89,7 @@ class CrtCounters(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
-MAT_MATTE, MAT_EMISSIVE = 1, 8                      # MatType, materials.h:8-18
+MAT_MATTE, MAT_MIRROR, MAT_EMISSIVE = 1, 2, 8        # MatType, materials.h:8-18
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity", "<f4"), ("sigma", "<f4")])
 assert MATERIAL_DTYPE.itemsize == 24
 

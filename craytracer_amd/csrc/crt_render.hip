@@ -178,14 +178,14 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
         const unsigned pixel = p % rd.npix, samp = first_sample + p / rd.npix;
         V3 beta = v3p(rd.beta + 3 * (size_t)p);
         V3 L = v3p(rd.L + 3 * (size_t)p);
-        unsigned good = rd.good[p];
+        unsigned good = rd.good[p] & 0x7FFFFFFFu;
+        bool spec = (rd.good[p] >> 31) != 0;                      /* sampled_flags & (SPECULAR | GLOSSY) of the previous bounce */
         const bool is_hit = hit.obj >= 0;
         ShadeObj so; so.type = -1; so.mat = 0;
         crt_material mat; mat.type = 0;
         if (is_hit) { so = rd.objs[hit.obj]; mat = rd.mats[so.mat]; }
-        /* emitted / environment light: bounce 0 only -- a Lambertian lobe never sets the SPECULAR or
-         * GLOSSY flag that re-enables it on later bounces (trace.h:419) */
-        if (bounce == 0) {
+        /* emitted / environment light: on bounce 0, and after a specular lobe was sampled (trace.h:419) */
+        if (bounce == 0 || spec) {
             if (is_hit) {
                 if (mat.type == CRT_MAT_EMISSIVE) {
                     V3 inc = scale(v3p(mat.color), mat.intensity);
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             const float dp = dot(normal, tangent);
             if (dp != 0.0f) tangent = normalize(sub(tangent, scale(normal, dp)));
             const V3 binormal = normalize(cross(normal, tangent));
-            /* ---- computeScatteringFunc: MATTE, sigma 0 -> one Lambertian (materials.cpp:116-124) ---- */
+            /* ---- computeScatteringFunc: MATTE, sigma 0 -> one Lambertian; MIRROR -> one SpecularReflection (materials.cpp:116-136) ---- */
             const V3 cd = v3p(mat.color);
             const unsigned dim0 = DIM_BOUNCE0 + DIMS_PER_BOUNCE * (unsigned)bounce;
             #define RNG(d) crt_rng(rd.seed_lo, rd.seed_hi, pixel, samp, dim0 + (d))
             const float ls0 = RNG(DIM_LIGHT), ls1 = RNG(DIM_LIGHT + 1);
             /* scatter_sample (trace.h:469) is drawn and never used: dimensions DIM_SCATTER, +1 stay reserved */
             /* ---- uniformSampleOneLight, trace.h:359-397 ---- */
-            if (rd.num_lights > 0) {
+            if (rd.num_lights > 0 && mat.type != CRT_MAT_MIRROR) {                  /* trace.h:470 */
                 const float u = RNG(DIM_PICK);
                 int li = rd.num_lights - 1;                       /* the reference leaves light_index unset when no interval matches */
                 float sel_pdf = rd.lights[li].power;
@@ -303,15 +303,24 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                     }
                 }
             }
-            /* ---- BSDF_sample_f (reflection.cpp:750-811) with the one Lambertian lobe ---- */
+            /* ---- BSDF_sample_f (reflection.cpp:750-811) with the material's one lobe ---- */
             const float bs0 = RNG(DIM_BSDF), bs1 = RNG(DIM_BSDF + 1);
             const V3 wo_l = v3(dot(wo, tangent), dot(wo, binormal), dot(wo, normal));    /* transposeTransform */
             alive = false;
             if (wo_l.z != 0.0f) {
-                const float two_z = fabsf(wo_l.z);                /* Lambertian_sample_f flips tmp_wo into the upper hemisphere */
-                V3 f = scale(cd, (float)RD_INV_PI);
-                const V3 wi_l = sample_hemisphere(bs0, bs1);
-                const float pdf = (wi_l.z * two_z > 0.0f) ? (float)((double)fabsf(wi_l.z) * RD_INV_PI) : 0.0f;   /* cosHemispherePdf */
+                V3 f, wi_l; float pdf;
+                if (mat.type == CRT_MAT_MIRROR) {                 /* SpecularReflection_sample_f, reflection.cpp:234-242 */
+                    spec = true;                                  /* getBxDFFlagsFromType: REFLECTION | SPECULAR */
+                    wi_l = v3(-wo_l.x, -wo_l.y, wo_l.z);
+                    f = scale(cd, 1.0f / fabsf(wi_l.z));
+                    pdf = 1.0f;
+                } else {                                          /* Lambertian_sample_f, reflection.cpp:177-189 */
+                    spec = false;
+                    const float two_z = fabsf(wo_l.z);            /* tmp_wo flipped into the upper hemisphere */
+                    f = scale(cd, (float)RD_INV_PI);
+                    wi_l = sample_hemisphere(bs0, bs1);
+                    pdf = (wi_l.z * two_z > 0.0f) ? (float)((double)fabsf(wi_l.z) * RD_INV_PI) : 0.0f;   /* cosHemispherePdf */
+                }
                 if (pdf != 0.0f && !is_black(f)) {
                     const V3 wi = ortho(tangent, binormal, normal, wi_l);
                     f = scale(f, fabsf(dot(wi, normal)) / pdf);   /* trace.h:494 */
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
         }
         rd.beta[3 * (size_t)p] = beta.x; rd.beta[3 * (size_t)p + 1] = beta.y; rd.beta[3 * (size_t)p + 2] = beta.z;
         rd.L[3 * (size_t)p] = L.x; rd.L[3 * (size_t)p + 1] = L.y; rd.L[3 * (size_t)p + 2] = L.z;
-        rd.good[p] = good;
+        rd.good[p] = good | (spec ? 0x80000000u : 0u);
     }
     unsigned ns, ss;
     queue_push2((unsigned long long*)rd.counters, push_next, push_shadow, &ns, &ss);
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256) void k_pt_finish(RenderDev rd, unsigned spp, u
     for (unsigned s = 0; s < spp; s++) {
         const size_t p = (size_t)s * rd.npix + pixel;
         V3 L = v3p(rd.L + 3 * p);
-        const unsigned good = rd.good[p];
+        const unsigned good = rd.good[p] & 0x7FFFFFFFu;
         if (good > 0) L = scale(L, 1.0f / (float)(int)good);
         V3 color = add(v3(0.f, 0.f, 0.f), L);
         if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z))
@@ -449,7 +458,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (4 + 8ull * ((unsigned long long)d->max_depth + 1) > 0xFFFFFFFFull) return CRT_E_TOOBIG;
     for (int m = 0; m < d->num_materials; m++) {
         const crt_material& mt = d->materials[m];
-        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE) return CRT_E_UNSUPPORTED;
+        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR) return CRT_E_UNSUPPORTED;
         if (mt.type == CRT_MAT_MATTE && mt.sigma != 0.0f) return CRT_E_UNSUPPORTED;       /* Oren-Nayar */
     }
     std::vector<ShadeObj> objs((size_t)in->num_obj);

@@ -4,7 +4,7 @@
  *
  * Follows, function by function: threadFunc's per-pixel body (main.cpp:102-141), pathTrace
  * (trace.h:399-532), uniformSampleOneLight (trace.h:359-397), estimateDirect (trace.h:221-357),
- * computeLocalBasis (trace.h:132-146), computeScatteringFunc MATTE (materials.cpp:116-128),
+ * computeLocalBasis (trace.h:132-146), computeScatteringFunc MATTE / MIRROR (materials.cpp:116-136),
  * BSDF_f / BSDF_sample_f / Lambertian_* (reflection.cpp:719-811,:159-189,:6-21), the ShadeRec tails
  * of the intersectors (triangle.cpp:154-168,:185-204, rect.cpp:3-47, sphere.cpp:3-31), the sampling
  * maps (sampling.cpp:606-618), getVec3InLocalBasis (util/math.cpp:31-39), the light set-up
@@ -193,21 +193,30 @@ float cosHemispherePdf(const vec3 wi, const vec3 wo)
     return (wi[2] * wo[2] > 0.0f) ? fabsf(wi[2]) * INV_PI : 0.0f;
 }
 
-/* BSDF_sample_f with num_bxdf == 1, LAMBERTIAN */
-float BSDF_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const ShadeRec* sr)
+enum { BSDF_NONE = 0, BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };   /* reflection.h:8-17 */
+
+/* BSDF_sample_f with num_bxdf == 1: LAMBERTIAN, or SPECULAR_REFLECTION when `mirror` */
+float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr, bool mirror)
 {
+    *sampled_flags = mirror ? (BSDF_REFLECTION | BSDF_SPECULAR) : (BSDF_REFLECTION | BSDF_DIFFUSE);   /* getBxDFFlagsFromType */
     vec3 wi_local, wo_local;
     transposeTransform(wo_local, sr->b_tangent, sr->b_binormal, sr->b_normal, wo);
     if (wo_local[2] == 0.0f) { vec3_copy(f, BLACK); return 0.0f; }   /* the reference returns with f unset; the caller only tests pdf */
     vec3_copy(f, BLACK);
-    /* Lambertian_sample_f */
-    vec3 tmp_wo;
-    vec3_copy(tmp_wo, wo_local);
-    if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
-    vec3_copy(f, sr->cd);
-    vec3_scale(f, f, INV_PI);
-    mapSampleToHemisphere(wi_local, sample);
-    float pdf = cosHemispherePdf(wi_local, tmp_wo);
+    float pdf;
+    if (mirror) {                                                  /* SpecularReflection_sample_f, reflection.cpp:234-242 */
+        vec3_assign(wi_local, -wo_local[0], -wo_local[1], wo_local[2]);
+        vec3_scale(f, sr->cd, 1.0f / fabsf(wi_local[2]));
+        pdf = 1.0f;
+    } else {                                                       /* Lambertian_sample_f */
+        vec3 tmp_wo;
+        vec3_copy(tmp_wo, wo_local);
+        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
+        vec3_copy(f, sr->cd);
+        vec3_scale(f, f, INV_PI);
+        mapSampleToHemisphere(wi_local, sample);
+        pdf = cosHemispherePdf(wi_local, tmp_wo);
+    }
     if (pdf == 0.0f) { vec3_copy(f, BLACK); return pdf; }
     orthoNormalTransform(wi, sr->b_tangent, sr->b_binormal, sr->b_normal, wi_local);
     return pdf;
@@ -334,13 +343,15 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
     vec3 beta = {1.0f, 1.0f, 1.0f};
     crt_ray ray = primary_ray;
     int good_paths = 0;
+    int sampled_flags = BSDF_NONE;
+    const int excluded_from_direct = BSDF_SPECULAR | BSDF_GLOSSY;
     for (int bounces = 0; ; bounces++) {
         ShadeRec sr;
         crt_hit hit;
         oracle_intersect(S.scene, &ray, 1, &hit, CRT_TRAVERSE_EXACT, 0, 1);
         float t = hit.t;
         if (t < TMAX) fillShadeRec(S, &sr, ray, hit);
-        if (bounces == 0) {                                        /* sampled_flags never holds SPECULAR / GLOSSY here */
+        if (bounces == 0 || (sampled_flags & excluded_from_direct)) {
             if (t < TMAX) {
                 if (sr.mat->type == CRT_MAT_EMISSIVE) {
                     vec3 inc_radiance;
@@ -365,7 +376,7 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         const uint32_t dim0 = 4 + 8 * (uint32_t)bounces;
         vec2 light_sample = { rng(dim0 + 0), rng(dim0 + 1) };
         /* scatter_sample: dim0 + 2, dim0 + 3, drawn by the reference and unused */
-        {
+        if (sr.mat->type != CRT_MAT_MIRROR) {
             vec3 contrib;
             uniformSampleOneLight(S, contrib, light_sample, &sr, rng(dim0 + 6));
             vec3_mult(contrib, contrib, beta);
@@ -375,7 +386,7 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         vec3 wo, wi, f;
         vec3_negate(wo, ray.d);
         vec2 sample = { rng(dim0 + 4), rng(dim0 + 5) };
-        float pdf = BSDF_sample_f(f, wi, wo, sample, &sr);
+        float pdf = BSDF_sample_f(f, wi, &sampled_flags, wo, sample, &sr, sr.mat->type == CRT_MAT_MIRROR);
         if (vec3_equal(f, BLACK) || pdf == 0.0f) break;
         vec3_scale(f, f, fabsf(vec3_dot(wi, sr.normal)) / pdf);
         vec3_mult(beta, beta, f);
@@ -514,13 +525,26 @@ float oracle_trace_lambertian(const float* cd, const float* basis, const float* 
     vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
     vec3_copy(sr.cd, cd);
     vec3 wi = {0.0f, 0.0f, 0.0f};
-    float pdf = BSDF_sample_f(f_out, wi, wo, sample, &sr);
+    int flags = 0;
+    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, false);
     vec3_copy(wi_out, wi);
     vec3 cur_f;                                                    /* BSDF_f as estimateDirect uses it */
     vec3_copy(cur_f, sr.cd);
     vec3_scale(cur_f, cur_f, INV_PI);
     vec3_copy(f_eval, BLACK);
     vec3_add(f_eval, f_eval, cur_f);
+    return pdf;
+}
+
+float oracle_trace_mirror(const float* cr, const float* basis, const float* wo, float* f_out, float* wi_out, int* flags)
+{
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
+    vec3_copy(sr.cd, cr);
+    vec3 wi = {0.0f, 0.0f, 0.0f};
+    const vec2 sample = {0.5f, 0.5f};
+    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, true);
+    vec3_copy(wi_out, wi);
     return pdf;
 }
 

@@ -526,6 +526,26 @@ REF_API float ref_lambertian_bsdf(const float* cd, const float* basis, const flo
     return pdf;
 }
 
+/* BSDF with one SpecularReflection lobe (BSDF_addSpecularReflection, what computeScatteringFunc builds for MIRROR) */
+REF_API float ref_mirror_bsdf(const float* cr, const float* basis, const float* wo, float* f_out, float* wi_out, int* flags_out)
+{
+    static bool pool = initBSDFMem(1, 4);
+    (void)pool;
+    BSDF bsdf;
+    bsdf.num_bxdf = 0;
+    memcpy(bsdf.tangent, basis, 12); memcpy(bsdf.binormal, basis + 3, 12); memcpy(bsdf.normal, basis + 6, 12);
+    vec3 c = { cr[0], cr[1], cr[2] };
+    BSDF_addSpecularReflection(&bsdf, c);
+    vec3 f = { 0, 0, 0 }, wi = { 0, 0, 0 }, w = { wo[0], wo[1], wo[2] };
+    vec2 smp = { 0.5f, 0.5f };
+    BxDFFlags flags = BSDF_NONE;
+    float pdf = BSDF_sample_f(f, wi, &flags, w, smp, &bsdf);
+    memcpy(f_out, f, 12); memcpy(wi_out, wi, 12);
+    *flags_out = (int)flags;
+    BSDF_freeBxDFs(&bsdf);
+    return pdf;
+}
+
 /* ---- image state: the reference's own imagestate.h ------------------------- */
 REF_API int ref_save_image_state(float* color_buffer, int num_samples, int width, int height, const char* file_name)
 {

@@ -83,6 +83,8 @@ def _load_oracle(path):
         L.oracle_trace_local_basis.restype = None
         L.oracle_trace_lambertian.argtypes = [vp] * 7
         L.oracle_trace_lambertian.restype = C.c_float
+        L.oracle_trace_mirror.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+        L.oracle_trace_mirror.restype = C.c_float
     return L
 
 
@@ -127,6 +129,8 @@ def ref():
         L.ref_vec3_in_local_basis.restype = None
         L.ref_lambertian_bsdf.argtypes = [vp] * 7
         L.ref_lambertian_bsdf.restype = C.c_float
+        L.ref_mirror_bsdf.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+        L.ref_mirror_bsdf.restype = C.c_float
         _ref = L
     return _ref
 

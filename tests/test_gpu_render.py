@@ -64,6 +64,20 @@ def test_room_with_every_light_kind():
     assert st["rays_shadow"] > 0
 
 
+def test_mirrors():
+    """MIRROR: no direct light at the hit, specular reflection, and the emitted light / sky seen through
+    it on the next bounce (sampled_flags & SPECULAR, trace.h:419)."""
+    si, desc, pos, look = scenes.render_room(24, 48, max_depth=6, rng_seed=12, mirrors=True)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 96, 96)
+    got, _, _ = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [4])
+    want = ol.OracleScene(si, api.ACCEL_BVH4).render(desc, cam, flm, 0, 4)
+    compare(got, want)
+    _, plain, _, _ = scenes.render_room(24, 48, max_depth=6, rng_seed=12, mirrors=False)
+    other = ol.OracleScene(si, api.ACCEL_BVH4).render(plain, cam, flm, 0, 4)
+    assert not ol.same_bits(want, other)
+
+
 def test_flat_triangles_keep_their_winding_normal():
     si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
@@ -142,7 +156,7 @@ def test_unsupported_scenes_are_refused():
         api.Renderer(scene, bad, cam, flm)
     assert e.value.code == -4
     mats = desc.materials.copy()
-    mats[1]["type"] = 2                                              # MIRROR
+    mats[1]["type"] = 4                                              # TRANSPARENT
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
     assert e.value.code == -4

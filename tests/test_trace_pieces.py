@@ -90,3 +90,21 @@ def test_lambertian_bsdf():
         if pb != 0.0:
             assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
         assert ol.same_bits(ea, eb)
+
+
+def test_mirror_bsdf():
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(7)
+    for k in range(3000):
+        n = rng.standard_normal(3).astype(np.float32); n /= np.linalg.norm(n)
+        t = np.cross(n, rng.standard_normal(3)).astype(np.float32); t /= np.linalg.norm(t)
+        b = np.cross(n, t).astype(np.float32)
+        basis = np.concatenate([t, b, n]).astype(np.float32)
+        wo = rng.standard_normal(3).astype(np.float32); wo /= np.linalg.norm(wo)
+        cr = rng.random(3, dtype=np.float32)
+        fa, wa, fb, wb = (np.zeros(3, np.float32) for _ in range(4))
+        ga, gb = C.c_int(), C.c_int()
+        pa = L.oracle_trace_mirror(_p(cr), _p(basis), _p(wo), _p(fa), _p(wa), C.byref(ga))
+        pb = R.ref_mirror_bsdf(_p(cr), _p(basis), _p(wo), _p(fb), _p(wb), C.byref(gb))
+        assert np.float32(pa) == np.float32(pb) == 1.0 and ga.value == gb.value == 17      # REFLECTION | SPECULAR
+        assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
