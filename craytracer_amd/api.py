@@ -89,9 +89,10 @@ class CrtCounters(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
-MAT_MATTE, MAT_MIRROR, MAT_EMISSIVE = 1, 2, 8        # MatType, materials.h:8-18
-MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity", "<f4"), ("sigma", "<f4")])
-assert MATERIAL_DTYPE.itemsize == 24
+MAT_MATTE, MAT_MIRROR, MAT_TRANSPARENT, MAT_EMISSIVE = 1, 2, 4, 8        # MatType, materials.h:8-18
+MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity", "<f4"), ("sigma", "<f4"),
+                           ("ior_in", "<f4"), ("ior_out", "<f4")])
+assert MATERIAL_DTYPE.itemsize == 32
 
 
 class CrtRenderDesc(C.Structure):
@@ -327,12 +328,14 @@ class RenderDesc:
         self.c = c
 
 
-def material(type_, color, intensity=0.0, sigma=0.0):
+def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0):
     m = np.zeros(1, MATERIAL_DTYPE)[0]
     m["type"] = type_
     m["color"] = np.asarray(color, np.float32)
     m["intensity"] = intensity
     m["sigma"] = sigma
+    m["ior_in"] = ior_in
+    m["ior_out"] = ior_out
     return m
 
 

@@ -76,6 +76,22 @@ __device__ __forceinline__ V3 sample_hemisphere(float s0, float s1)
     return v3(d[0], d[1], sqrtf((0.0f > zz) ? 0.0f : zz));            /* max(0, .), util/util.h:14 */
 }
 
+/* calcFresnelDielectric, reflection.cpp:52-76, for the tangent-space normal (0, 0, +-1) */
+__device__ __forceinline__ float fresnel_dielectric(float nz, float woz, float etaT, float etaI)
+{
+    float cos_theta_i = nz * woz;                                 /* vec3_dot with n = (0, 0, nz): 0*x + 0*y + nz*z */
+    if (cos_theta_i < 0.0f) { const float tmp = etaI; etaI = etaT; etaT = tmp; cos_theta_i = fabsf(cos_theta_i); }
+    const float s2 = 1.0f - cos_theta_i * cos_theta_i;
+    const float sin_theta_i = sqrtf((0.0f > s2) ? 0.0f : s2);
+    const float sin_theta_t = etaI / etaT * sin_theta_i;
+    if (sin_theta_t >= 1.0f) return 1.0f;
+    const float c2 = 1 - sin_theta_t * sin_theta_t;
+    const float cos_theta_t = sqrtf((0.0f > c2) ? 0.0f : c2);
+    const float r_parl = ((etaT * cos_theta_i) - (etaI * cos_theta_t)) / ((etaT * cos_theta_i) + (etaI * cos_theta_t));
+    const float r_perp = ((etaI * cos_theta_i) - (etaT * cos_theta_t)) / ((etaI * cos_theta_i) + (etaT * cos_theta_t));
+    return (r_parl * r_parl + r_perp * r_perp) / 2;
+}
+
 /* crt_rng: DESIGN.md "N1".  Three rounds of the murmur3 finaliser over (seed, pixel, sample, dim). */
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             const float ls0 = RNG(DIM_LIGHT), ls1 = RNG(DIM_LIGHT + 1);
             /* scatter_sample (trace.h:469) is drawn and never used: dimensions DIM_SCATTER, +1 stay reserved */
             /* ---- uniformSampleOneLight, trace.h:359-397 ---- */
-            if (rd.num_lights > 0 && mat.type != CRT_MAT_MIRROR) {                  /* trace.h:470 */
+            if (rd.num_lights > 0 && mat.type != CRT_MAT_MIRROR && mat.type != CRT_MAT_TRANSPARENT) {   /* trace.h:470 */
                 const float u = RNG(DIM_PICK);
                 int li = rd.num_lights - 1;                       /* the reference leaves light_index unset when no interval matches */
                 float sel_pdf = rd.lights[li].power;
@@ -314,6 +330,23 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                     wi_l = v3(-wo_l.x, -wo_l.y, wo_l.z);
                     f = scale(cd, 1.0f / fabsf(wi_l.z));
                     pdf = 1.0f;
+                } else if (mat.type == CRT_MAT_TRANSPARENT) {     /* SpecularTransmission_sample_f, `thin` branch, reflection.cpp:243-269 */
+                    spec = true;                                  /* REFLECTION | TRANSMISSION | SPECULAR */
+                    const float nz = wo_l.z < 0.0f ? -1.0f : 1.0f;
+                    /* vec3_dot(normal, wo) with normal = (0, 0, 1) is 0*x + 0*y + 1*z: the sign test reads that sum */
+                    const float kr = fresnel_dielectric(nz, wo_l.z, mat.ior_in, mat.ior_out);
+                    const float u = RNG(DIM_SCATTER);             /* the reference's rand() (reflection.cpp:254) */
+                    if (u <= kr) {
+                        wi_l = v3(-wo_l.x, -wo_l.y, wo_l.z);
+                        f = scale(v3(1.0f, 1.0f, 1.0f), kr / fabsf(wi_l.z));
+                        pdf = kr;
+                    } else {
+                        const float eta = mat.ior_out / mat.ior_in;
+                        wi_l = neg(wo_l);
+                        f = scale(v3(1.0f, 1.0f, 1.0f), 1.0f - kr);
+                        f = scale(f, (eta * eta) / fabsf(wi_l.z));
+                        pdf = 1.0f - kr;
+                    }
                 } else {                                          /* Lambertian_sample_f, reflection.cpp:177-189 */
                     spec = false;
                     const float two_z = fabsf(wo_l.z);            /* tmp_wo flipped into the upper hemisphere */
@@ -458,7 +491,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (4 + 8ull * ((unsigned long long)d->max_depth + 1) > 0xFFFFFFFFull) return CRT_E_TOOBIG;
     for (int m = 0; m < d->num_materials; m++) {
         const crt_material& mt = d->materials[m];
-        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR) return CRT_E_UNSUPPORTED;
+        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT) return CRT_E_UNSUPPORTED;
         if (mt.type == CRT_MAT_MATTE && mt.sigma != 0.0f) return CRT_E_UNSUPPORTED;       /* Oren-Nayar */
     }
     std::vector<ShadeObj> objs((size_t)in->num_obj);

@@ -208,7 +208,7 @@ def cornell_camera(width, height, fov=0.6911, L=None):
 
 
 def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intensity=0.25, samples_in_flight=0,
-                tri_type=None, mirrors=False):
+                tri_type=None, mirrors=False, glass=False):
     """A displaced blob (TRIANGLE objects) in a unit room of 12 triangles, two matte spheres, a sphere
     light, a disk light, a rectangle light under the ceiling (slightly tilted, so its box is not flat)
     and a constant environment light seen through nothing (the room is closed) but sampled:
@@ -228,7 +228,9 @@ def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intens
     mat_of += [3] * len(blob)
     sl.rectangle((0.35, 0.97, 0.35), (0.3, 0.02, 0.0), (0.0, 0.0, 0.3)); mat_of.append(4)
     sl.rectangle((0.35, 0.97, 0.65), (0.3, 0.02, 0.0), (0.0, 0.0, -0.3)); mat_of.append(4)   # same place, opposite normal
-    sl.sphere((0.18, 0.12, 0.75), 0.12); mat_of.append(5)
+    sl.sphere((0.18, 0.12, 0.75), 0.12); mat_of.append(9 if glass else 5)
+    if glass:                                             # a thin pane across the room in front of the camera
+        sl.rectangle((0.1, 0.1, 0.8), (0.8, 0.0, 0.02), (0.0, 0.7, 0.0)); mat_of.append(9)
     sl.sphere((0.82, 0.10, 0.70), 0.10); mat_of.append(8 if mirrors else 0)
     sl.sphere((0.85, 0.80, 0.20), 0.05); mat_of.append(6)                                   # sphere light
     sl.disk((0.02, 0.5, 0.5), _normalize32((1.0, 0.1, 0.0)), 0.15); mat_of.append(7)            # disk light on the left wall
@@ -238,6 +240,7 @@ def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intens
         api.material(api.MAT_EMISSIVE, (1.0, 0.85, 0.5), 12.0), api.material(api.MAT_MATTE, (0.2, 0.3, 0.7)),
         api.material(api.MAT_EMISSIVE, (0.6, 0.8, 1.0), 40.0), api.material(api.MAT_EMISSIVE, (1.0, 0.4, 0.3), 6.0),
         api.material(api.MAT_MIRROR, (0.9, 0.9, 0.85)),
+        api.material(api.MAT_TRANSPARENT, (1.0, 1.0, 1.0), ior_in=1.5, ior_out=1.0),
     ], api.MATERIAL_DTYPE)
     si = sl.to_input()
     env = ((1.0, 1.0, 1.0), env_intensity, 3.5) if env_intensity is not None else None

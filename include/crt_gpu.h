@@ -256,7 +256,7 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
  *   geometry  TRIANGLE, FLAT_TRIANGLE, RECTANGLE, SPHERE; DISK only with an EMISSIVE material;
  *   materials MATTE with sigma == 0 and no texture (Lambertian, materials.cpp:116-128), MIRROR (specular
- *             reflection, materials.cpp:129-136), EMISSIVE;
+ *             reflection, materials.cpp:129-136), TRANSPARENT (thin specular transmission, :137-141), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
  *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform).
  * Random numbers: the reference draws from per-thread sample tables (Sampler_getSample) and from libc
@@ -264,9 +264,10 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * crt_rng(seed, pixel, sample, dimension) (definition in DESIGN.md "N1"), so an image is a pure
  * function of (scene, camera, seed, sample range).  Images therefore agree with the reference's in
  * distribution, not sample for sample. */
-enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_MIRROR = 2, CRT_MAT_EMISSIVE = 8 };     /* MatType, materials.h:8-18 */
-/* MATTE: color = Matte.color (materials.h Matte_s).  MIRROR: color = Mirror.color.  EMISSIVE: Emissive.color, .intensity. */
-typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; } crt_material;
+enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_MIRROR = 2, CRT_MAT_TRANSPARENT = 4, CRT_MAT_EMISSIVE = 8 };     /* MatType, materials.h:8-18 */
+/* MATTE: color = Matte.color, sigma (materials.h Matte_s).  MIRROR: color = Mirror.color.  TRANSPARENT: ior_in, ior_out
+ * (Transparent_s; the reference's `thin` model, reflection.cpp:243-269, ignores cf_in / cf_out).  EMISSIVE: Emissive.color, .intensity. */
+typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; float ior_in; float ior_out; } crt_material;
 
 typedef struct crt_render_desc {
     const crt_scene_input* objects;      /* the insertion-order arrays the scene was built from */

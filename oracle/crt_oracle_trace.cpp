@@ -4,7 +4,7 @@
  *
  * Follows, function by function: threadFunc's per-pixel body (main.cpp:102-141), pathTrace
  * (trace.h:399-532), uniformSampleOneLight (trace.h:359-397), estimateDirect (trace.h:221-357),
- * computeLocalBasis (trace.h:132-146), computeScatteringFunc MATTE / MIRROR (materials.cpp:116-136),
+ * computeLocalBasis (trace.h:132-146), computeScatteringFunc MATTE / MIRROR / TRANSPARENT (materials.cpp:116-141),
  * BSDF_f / BSDF_sample_f / Lambertian_* (reflection.cpp:719-811,:159-189,:6-21), the ShadeRec tails
  * of the intersectors (triangle.cpp:154-168,:185-204, rect.cpp:3-47, sphere.cpp:3-31), the sampling
  * maps (sampling.cpp:606-618), getVec3InLocalBasis (util/math.cpp:31-39), the light set-up
@@ -18,7 +18,7 @@
  *
  * Deliberate differences from the reference, shared with the product (DESIGN.md "N1"):
  *   - random numbers come from oracle_rng(seed, pixel, sample, dim) instead of the Sampler tables and
- *     libc rand();
+ *     libc rand() (trace.h:371,:516; reflection.cpp:254);
  *   - ShadeRec.dpdu of TRIANGLE / FLAT_TRIANGLE hits, which the reference leaves uninitialised
  *     (triangle.cpp:154-204 never write it), is normalize(v1 - v0);
  *   - when no CDF interval matches in uniformSampleOneLight (the reference leaves light_index
@@ -195,10 +195,36 @@ float cosHemispherePdf(const vec3 wi, const vec3 wo)
 
 enum { BSDF_NONE = 0, BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };   /* reflection.h:8-17 */
 
-/* BSDF_sample_f with num_bxdf == 1: LAMBERTIAN, or SPECULAR_REFLECTION when `mirror` */
-float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr, bool mirror)
+/* calcFresnelDielectric, reflection.cpp:52-76 */
+float calcFresnelDielectric(const vec3 normal, const vec3 wo, float etaT, float etaI)
 {
-    *sampled_flags = mirror ? (BSDF_REFLECTION | BSDF_SPECULAR) : (BSDF_REFLECTION | BSDF_DIFFUSE);   /* getBxDFFlagsFromType */
+    vec3 n;
+    vec3_copy(n, normal);
+    float cos_theta_i = vec3_dot(n, wo);
+    if (cos_theta_i < 0.0f) {
+        float tmp = etaI; etaI = etaT; etaT = tmp;
+        vec3_negate(n, n);
+        cos_theta_i = fabsf(cos_theta_i);
+    }
+    float sin_theta_i = sqrtf(maxf(0.0f, 1.0f - cos_theta_i * cos_theta_i));
+    float sin_theta_t = etaI / etaT * sin_theta_i;
+    if (sin_theta_t >= 1.0f) return 1.0f;
+    float cos_theta_t = sqrtf(maxf(0.0f, 1 - sin_theta_t * sin_theta_t));
+    float r_parl = ((etaT * cos_theta_i) - (etaI * cos_theta_t)) / ((etaT * cos_theta_i) + (etaI * cos_theta_t));
+    float r_perp = ((etaI * cos_theta_i) - (etaT * cos_theta_t)) / ((etaI * cos_theta_i) + (etaT * cos_theta_t));
+    return (r_parl * r_parl + r_perp * r_perp) / 2;
+}
+
+enum { LOBE_LAMBERTIAN = 0, LOBE_SPECULAR_REFLECTION = 1, LOBE_SPECULAR_TRANSMISSION = 2 };
+struct Lobe { int kind; float ior_in, ior_out; float rand_float; };   /* rand_float: the value SpecularTransmission_sample_f draws from rand() */
+
+/* BSDF_sample_f with num_bxdf == 1 */
+float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr, const Lobe& lobe)
+{
+    const bool mirror = lobe.kind == LOBE_SPECULAR_REFLECTION;
+    *sampled_flags = mirror ? (BSDF_REFLECTION | BSDF_SPECULAR)                                        /* getBxDFFlagsFromType */
+                   : lobe.kind == LOBE_SPECULAR_TRANSMISSION ? (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR)   /* the lobe also reflects */
+                   : (BSDF_REFLECTION | BSDF_DIFFUSE);
     vec3 wi_local, wo_local;
     transposeTransform(wo_local, sr->b_tangent, sr->b_binormal, sr->b_normal, wo);
     if (wo_local[2] == 0.0f) { vec3_copy(f, BLACK); return 0.0f; }   /* the reference returns with f unset; the caller only tests pdf */
@@ -208,6 +234,23 @@ float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const ve
         vec3_assign(wi_local, -wo_local[0], -wo_local[1], wo_local[2]);
         vec3_scale(f, sr->cd, 1.0f / fabsf(wi_local[2]));
         pdf = 1.0f;
+    } else if (lobe.kind == LOBE_SPECULAR_TRANSMISSION) {          /* SpecularTransmission_sample_f, `thin` (reflection.cpp:243-269) */
+        const vec3 WHITE = {1.0f, 1.0f, 1.0f};
+        vec3 normal = {0.0f, 0.0f, 1.0f};
+        float cos_theta_o = vec3_dot(normal, wo_local);
+        if (cos_theta_o < 0.0f) vec3_negate(normal, normal);
+        float kr = calcFresnelDielectric(normal, wo_local, lobe.ior_in, lobe.ior_out);
+        if (lobe.rand_float <= kr) {
+            vec3_assign(wi_local, -wo_local[0], -wo_local[1], wo_local[2]);
+            vec3_scale(f, WHITE, kr / fabsf(wi_local[2]));
+            pdf = kr;
+        } else {
+            float eta = lobe.ior_out / lobe.ior_in;
+            vec3_negate(wi_local, wo_local);
+            vec3_scale(f, WHITE, 1.0f - kr);
+            vec3_scale(f, f, (eta * eta) / fabsf(wi_local[2]));
+            pdf = 1.0f - kr;
+        }
     } else {                                                       /* Lambertian_sample_f */
         vec3 tmp_wo;
         vec3_copy(tmp_wo, wo_local);
@@ -376,7 +419,7 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         const uint32_t dim0 = 4 + 8 * (uint32_t)bounces;
         vec2 light_sample = { rng(dim0 + 0), rng(dim0 + 1) };
         /* scatter_sample: dim0 + 2, dim0 + 3, drawn by the reference and unused */
-        if (sr.mat->type != CRT_MAT_MIRROR) {
+        if (!(sr.mat->type == CRT_MAT_MIRROR || sr.mat->type == CRT_MAT_TRANSPARENT)) {
             vec3 contrib;
             uniformSampleOneLight(S, contrib, light_sample, &sr, rng(dim0 + 6));
             vec3_mult(contrib, contrib, beta);
@@ -386,7 +429,13 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         vec3 wo, wi, f;
         vec3_negate(wo, ray.d);
         vec2 sample = { rng(dim0 + 4), rng(dim0 + 5) };
-        float pdf = BSDF_sample_f(f, wi, &sampled_flags, wo, sample, &sr, sr.mat->type == CRT_MAT_MIRROR);
+        Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f };
+        if (sr.mat->type == CRT_MAT_MIRROR) lobe.kind = LOBE_SPECULAR_REFLECTION;
+        if (sr.mat->type == CRT_MAT_TRANSPARENT) {
+            lobe.kind = LOBE_SPECULAR_TRANSMISSION; lobe.ior_in = sr.mat->ior_in; lobe.ior_out = sr.mat->ior_out;
+            lobe.rand_float = rng(dim0 + 2);                       /* in place of rand() inside the lobe */
+        }
+        float pdf = BSDF_sample_f(f, wi, &sampled_flags, wo, sample, &sr, lobe);
         if (vec3_equal(f, BLACK) || pdf == 0.0f) break;
         vec3_scale(f, f, fabsf(vec3_dot(wi, sr.normal)) / pdf);
         vec3_mult(beta, beta, f);
@@ -526,7 +575,8 @@ float oracle_trace_lambertian(const float* cd, const float* basis, const float* 
     vec3_copy(sr.cd, cd);
     vec3 wi = {0.0f, 0.0f, 0.0f};
     int flags = 0;
-    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, false);
+    const Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f };
+    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, lobe);
     vec3_copy(wi_out, wi);
     vec3 cur_f;                                                    /* BSDF_f as estimateDirect uses it */
     vec3_copy(cur_f, sr.cd);
@@ -543,7 +593,20 @@ float oracle_trace_mirror(const float* cr, const float* basis, const float* wo, 
     vec3_copy(sr.cd, cr);
     vec3 wi = {0.0f, 0.0f, 0.0f};
     const vec2 sample = {0.5f, 0.5f};
-    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, true);
+    const Lobe lobe = { LOBE_SPECULAR_REFLECTION, 1.0f, 1.0f, 0.0f };
+    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
+    vec3_copy(wi_out, wi);
+    return pdf;
+}
+float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, const float* basis, const float* wo,
+                               float* f_out, float* wi_out, int* flags)
+{
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
+    vec3 wi = {0.0f, 0.0f, 0.0f};
+    const vec2 sample = {0.5f, 0.5f};
+    const Lobe lobe = { LOBE_SPECULAR_TRANSMISSION, ior_in, ior_out, rand_float };
+    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
     vec3_copy(wi_out, wi);
     return pdf;
 }

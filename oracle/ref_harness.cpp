@@ -546,6 +546,29 @@ REF_API float ref_mirror_bsdf(const float* cr, const float* basis, const float* 
     return pdf;
 }
 
+/* BSDF with one SpecularTransmission lobe (what computeScatteringFunc builds for TRANSPARENT).  The lobe draws
+ * from libc rand(); srand(seed) first so that the caller knows the value. */
+REF_API float ref_transparent_bsdf(float ior_in, float ior_out, unsigned seed, const float* basis, const float* wo,
+                                   float* f_out, float* wi_out, int* flags_out)
+{
+    static bool pool = initBSDFMem(1, 4);
+    (void)pool;
+    BSDF bsdf;
+    bsdf.num_bxdf = 0;
+    memcpy(bsdf.tangent, basis, 12); memcpy(bsdf.binormal, basis + 3, 12); memcpy(bsdf.normal, basis + 6, 12);
+    vec3 cf = { 1.0f, 1.0f, 1.0f };
+    BSDF_addSpecularTransmission(&bsdf, ior_in, ior_out, cf, cf);
+    vec3 f = { 0, 0, 0 }, wi = { 0, 0, 0 }, w = { wo[0], wo[1], wo[2] };
+    vec2 smp = { 0.5f, 0.5f };
+    BxDFFlags flags = BSDF_NONE;
+    srand(seed);
+    float pdf = BSDF_sample_f(f, wi, &flags, w, smp, &bsdf);
+    memcpy(f_out, f, 12); memcpy(wi_out, wi, 12);
+    *flags_out = (int)flags;
+    BSDF_freeBxDFs(&bsdf);
+    return pdf;
+}
+
 /* ---- image state: the reference's own imagestate.h ------------------------- */
 REF_API int ref_save_image_state(float* color_buffer, int num_samples, int width, int height, const char* file_name)
 {

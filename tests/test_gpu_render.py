@@ -78,6 +78,17 @@ def test_mirrors():
     assert not ol.same_bits(want, other)
 
 
+def test_thin_transparent_surfaces():
+    """TRANSPARENT (the reference's `thin` specular transmission): Fresnel pick between mirror reflection and
+    straight-through transmission by one random number per bounce, no direct light at the hit."""
+    si, desc, pos, look = scenes.render_room(24, 48, max_depth=6, rng_seed=21, mirrors=True, glass=True)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 96, 96)
+    got, _, _ = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [4])
+    want = ol.OracleScene(si, api.ACCEL_BVH4).render(desc, cam, flm, 0, 4)
+    compare(got, want)
+
+
 def test_flat_triangles_keep_their_winding_normal():
     si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
@@ -156,7 +167,7 @@ def test_unsupported_scenes_are_refused():
         api.Renderer(scene, bad, cam, flm)
     assert e.value.code == -4
     mats = desc.materials.copy()
-    mats[1]["type"] = 4                                              # TRANSPARENT
+    mats[1]["type"] = 16                                             # PLASTIC
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
     assert e.value.code == -4

@@ -108,3 +108,35 @@ def test_mirror_bsdf():
         pb = R.ref_mirror_bsdf(_p(cr), _p(basis), _p(wo), _p(fb), _p(wb), C.byref(gb))
         assert np.float32(pa) == np.float32(pb) == 1.0 and ga.value == gb.value == 17      # REFLECTION | SPECULAR
         assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
+
+
+def test_transparent_bsdf():
+    """The `thin` SpecularTransmission lobe; its rand() is replayed: srand(seed) in the harness, the same
+    srand + rand through libc here."""
+    L, R = ol.oracle(), ol.ref()
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    RAND_MAX = 2147483647
+    rng = np.random.default_rng(8)
+    n_reflect = 0
+    for k in range(4000):
+        n = rng.standard_normal(3).astype(np.float32); n /= np.linalg.norm(n)
+        t = np.cross(n, rng.standard_normal(3)).astype(np.float32); t /= np.linalg.norm(t)
+        b = np.cross(n, t).astype(np.float32)
+        basis = np.concatenate([t, b, n]).astype(np.float32)
+        wo = rng.standard_normal(3).astype(np.float32); wo /= np.linalg.norm(wo)
+        if k % 4 == 0:                                         # grazing: large Fresnel reflectance
+            wo = (t * np.float32(0.995) + n * np.float32(0.0999) * (1 if k % 8 else -1)).astype(np.float32)
+        ior_in, ior_out = np.float32(1.0 + rng.random()), np.float32(1.0 + 0.6 * rng.random())
+        seed = int(rng.integers(1, 2**31))
+        libc.srand(seed)
+        rand_float = np.float32(np.float32(libc.rand()) / np.float32(RAND_MAX))
+        fa, wa, fb, wb = (np.zeros(3, np.float32) for _ in range(4))
+        ga, gb = C.c_int(), C.c_int()
+        pa = L.oracle_trace_transparent(ior_in, ior_out, rand_float, _p(basis), _p(wo), _p(fa), _p(wa), C.byref(ga))
+        pb = R.ref_transparent_bsdf(ior_in, ior_out, seed, _p(basis), _p(wo), _p(fb), _p(wb), C.byref(gb))
+        assert np.float32(pa) == np.float32(pb) and ga.value == gb.value == 19             # REFLECTION | TRANSMISSION | SPECULAR
+        if pb != 0.0:
+            assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
+        n_reflect += int(np.dot(wa, n) * np.dot(wo, n) > 0)
+    assert 100 < n_reflect < 3900

@@ -1,6 +1,6 @@
 """samples/sec/pixel of the wavefront path tracer (crt_renderer_*) on the courtyard stand-in, QBVH.
     python tools/bench_render.py [--copies 640 --lat 64 --lon 128] [--width 3840 --height 2160] [--spp 4] [--depth 5]
-Prints one JSON line; --check N compares the first N samples of a 256 x 144 image with the CPU oracle."""
+Prints one JSON line.  (The comparison with the CPU oracle lives in tests/test_gpu_render.py and in bench.py's cpu_baseline leg.)"""
 import argparse
 import json
 import os
@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--in-flight", type=int, default=0)
-    ap.add_argument("--check", type=int, default=0)
     a = ap.parse_args()
     t0 = time.time()
     si, desc, pos, look = scenes.courtyard_render(a.copies, a.lat, a.lon, max_depth=a.depth, samples_in_flight=a.in_flight)
@@ -52,15 +51,6 @@ def main():
         "ms_total": s1["ms_total"] - s0["ms_total"], "build_seconds": t_build,
         "mean_radiance": float(img.mean() / ns), "finite": bool(np.isfinite(img).all()),
     }
-    if a.check:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oraclelib as ol
-        flm2 = api.make_film(cam, 1.0, 256, 144)
-        r2 = api.Renderer(scene, desc, cam, flm2)
-        r2.render(a.check)
-        got, _ = r2.read()
-        want = ol.OracleScene(si, built=built).render(desc, cam, flm2, 0, a.check, nthreads=16)
-        out["oracle_check"] = {"samples": a.check, "pixels": 256 * 144, "bit_identical_pixels": float((got == want).all(axis=2).mean())}
     print(json.dumps(out))
 
 
