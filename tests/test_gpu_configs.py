@@ -69,3 +69,30 @@ def test_c2_analytic_1080p(accel):
     good = ~bad
     assert close(hits["beta"][good], want["beta"][good]).all() and close(hits["gamma"][good], want["gamma"][good]).all()
     sc.close()
+
+
+def test_c1_cornell_rendered_512x512_16spp():
+    """BASELINE.json configs[0] as a render: cornell_box.txt with its materials, 512 x 512, 16 spp, uniform grid,
+    path-traced by crt_renderer_* and by the oracle on the host cores: the two colour buffers are bit-identical.
+    (Through the grid the flat rectangles are partly missed, as in the reference -- test_c1_cornell_grid_512x512.)"""
+    import time
+    si, desc = scenes.cornell29_render(max_depth=5, seed=16)
+    cam, flm = scenes.cornell_camera(512, 512)
+    built = api.BuiltScene(si, api.ACCEL_GRID)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, desc, cam, flm)
+    r.render(1)
+    r.reset(0)
+    t0 = time.perf_counter()
+    r.render(16)
+    gpu_s = time.perf_counter() - t0
+    got, ns = r.read()
+    r.close()
+    t0 = time.perf_counter()
+    want = ol.OracleScene(si, built=built).render(desc, cam, flm, 0, 16, nthreads=16)
+    cpu_s = time.perf_counter() - t0
+    print("C1 render: GPU %.1f samples/s/pixel (%.3f s), oracle on 16 threads %.2f (%.1f s)" % (16 / gpu_s, gpu_s, 16 / cpu_s, cpu_s))
+    assert ns == 16 and np.isfinite(got).all() and got.max() > 0
+    assert ol.same_bits(got, want)
+    img = api.image_from_color_buffer(got, ns)
+    assert img.shape == (512, 512, 3) and img.max() == 255 and 20 < img.mean() < 235
