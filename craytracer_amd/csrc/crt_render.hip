@@ -76,6 +76,27 @@ __device__ __forceinline__ V3 sample_hemisphere(float s0, float s1)
     return v3(d[0], d[1], sqrtf((0.0f > zz) ? 0.0f : zz));            /* max(0, .), util/util.h:14 */
 }
 
+/* OrenNayar_f, reflection.cpp:191-214; sinTheta / cosPhi / sinPhi, util/math.h:13-36.  w: the vectors the
+ * reference hands it -- tangent space from BSDF_sample_f, WORLD space from BSDF_f (reflection.cpp:731 passes
+ * wi, wo, not wi_local, wo_local) */
+__device__ __forceinline__ float on_sin_theta(V3 w) { const float s2 = 1.0f - w.z * w.z; return sqrtf((0.0f > s2) ? 0.0f : s2); }
+__device__ __forceinline__ float on_clamp(float x) { return (x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x)); }
+__device__ __forceinline__ float oren_nayar_scale(V3 wi, V3 wo, float a, float b)
+{
+    const float sin_theta_i = on_sin_theta(wi), sin_theta_o = on_sin_theta(wo);
+    float max_cos = 0.0f;
+    if ((double)sin_theta_i > 1e-4 && (double)sin_theta_o > 1e-4) {
+        const float sin_phi_i = (sin_theta_i == 0) ? 0 : on_clamp(wi.y / sin_theta_i), cos_phi_i = (sin_theta_i == 0) ? 1 : on_clamp(wi.x / sin_theta_i);
+        const float sin_phi_o = (sin_theta_o == 0) ? 0 : on_clamp(wo.y / sin_theta_o), cos_phi_o = (sin_theta_o == 0) ? 1 : on_clamp(wo.x / sin_theta_o);
+        const float d_cos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
+        max_cos = (0.0f > d_cos) ? 0.0f : d_cos;
+    }
+    float sin_alpha, tan_beta;
+    if (fabsf(wi.z) > fabsf(wo.z)) { sin_alpha = sin_theta_o; tan_beta = sin_theta_i / fabsf(wi.z); }
+    else                           { sin_alpha = sin_theta_i; tan_beta = sin_theta_o / fabsf(wo.z); }
+    return (float)((double)(a + b * max_cos * sin_alpha * tan_beta) * RD_INV_PI);
+}
+
 /* calcFresnelDielectric, reflection.cpp:52-76, for the tangent-space normal (0, 0, +-1) */
 __device__ __forceinline__ float fresnel_dielectric(float nz, float woz, float etaT, float etaI)
 {
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             const V3 binormal = normalize(cross(normal, tangent));
             /* ---- computeScatteringFunc: MATTE, sigma 0 -> one Lambertian; MIRROR -> one SpecularReflection (materials.cpp:116-136) ---- */
             const V3 cd = v3p(mat.color);
+            const bool oren = mat.type == CRT_MAT_MATTE && mat.sigma != 0.0f;   /* BSDF_addOrenNayar; a, b sit in ior_in, ior_out of the device copy */
             const unsigned dim0 = DIM_BOUNCE0 + DIMS_PER_BOUNCE * (unsigned)bounce;
             #define RNG(d) crt_rng(rd.seed_lo, rd.seed_hi, pixel, samp, dim0 + (d))
             const float ls0 = RNG(DIM_LIGHT), ls1 = RNG(DIM_LIGHT + 1);
@@ -304,7 +326,8 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 const V3 Li = scale(v3p(lt.color), lt.intensity);
                 const V3 s2h = sub(sp, hp);
                 if (!(dot(s2h, sn) > 0.0f || dot(s2h, normal) < 0.0f) && lpdf > 0.0f && !is_black(Li)) {
-                    V3 f = scale(cd, (float)RD_INV_PI);           /* Lambertian_f, reflection.cpp:159-163 */
+                    V3 f = oren ? scale(cd, oren_nayar_scale(wi, wo, mat.ior_in, mat.ior_out))    /* OrenNayar_f on the WORLD vectors */
+                                : scale(cd, (float)RD_INV_PI);    /* Lambertian_f, reflection.cpp:159-163 */
                     f = scale(f, fabsf(dot(normal, wi)));
                     if (!is_black(f)) {
                         V3 radiance = mul(f, Li);
@@ -350,9 +373,10 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 } else {                                          /* Lambertian_sample_f, reflection.cpp:177-189 */
                     spec = false;
                     const float two_z = fabsf(wo_l.z);            /* tmp_wo flipped into the upper hemisphere */
-                    f = scale(cd, (float)RD_INV_PI);
                     wi_l = sample_hemisphere(bs0, bs1);
                     pdf = (wi_l.z * two_z > 0.0f) ? (float)((double)fabsf(wi_l.z) * RD_INV_PI) : 0.0f;   /* cosHemispherePdf */
+                    f = oren ? scale(cd, oren_nayar_scale(wi_l, wo_l, mat.ior_in, mat.ior_out))          /* OrenNayar_sample_f, :221-232 */
+                             : scale(cd, (float)RD_INV_PI);
                 }
                 if (pdf != 0.0f && !is_black(f)) {
                     const V3 wi = ortho(tangent, binormal, normal, wi_l);
@@ -492,7 +516,6 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     for (int m = 0; m < d->num_materials; m++) {
         const crt_material& mt = d->materials[m];
         if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT) return CRT_E_UNSUPPORTED;
-        if (mt.type == CRT_MAT_MATTE && mt.sigma != 0.0f) return CRT_E_UNSUPPORTED;       /* Oren-Nayar */
     }
     std::vector<ShadeObj> objs((size_t)in->num_obj);
     std::vector<LightRec> lights;
@@ -590,7 +613,15 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.color, 3 * (size_t)npix);
     bool ok = rc == CRT_OK;
     ok = ok && hipMemcpy(d_objs, objs.data(), objs.size() * sizeof(ShadeObj), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(d_mats, d->materials, (size_t)d->num_materials * sizeof(crt_material), hipMemcpyHostToDevice) == hipSuccess;
+    std::vector<crt_material> dev_mats(d->materials, d->materials + d->num_materials);
+    for (crt_material& m : dev_mats) {
+        if (m.type != CRT_MAT_MATTE || m.sigma == 0.0f) continue;
+        const float sigma_rad = m.sigma / 180.0f * (float)RD_PI;  /* BSDF_addOrenNayar, reflection.cpp:823-830; degToRad, util/math.h:65 */
+        const float sigma2 = sigma_rad * sigma_rad;
+        m.ior_in = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));   /* a */
+        m.ior_out = 0.45f * sigma2 / (sigma2 + 0.09f);            /* b */
+    }
+    ok = ok && hipMemcpy(d_mats, dev_mats.data(), dev_mats.size() * sizeof(crt_material), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(rd.counters, 0, 256) == hipSuccess;

@@ -208,7 +208,7 @@ def cornell_camera(width, height, fov=0.6911, L=None):
 
 
 def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intensity=0.25, samples_in_flight=0,
-                tri_type=None, mirrors=False, glass=False):
+                tri_type=None, mirrors=False, glass=False, rough=False):
     """A displaced blob (TRIANGLE objects) in a unit room of 12 triangles, two matte spheres, a sphere
     light, a disk light, a rectangle light under the ceiling (slightly tilted, so its box is not flat)
     and a constant environment light seen through nothing (the room is closed) but sampled:
@@ -242,6 +242,8 @@ def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intens
         api.material(api.MAT_MIRROR, (0.9, 0.9, 0.85)),
         api.material(api.MAT_TRANSPARENT, (1.0, 1.0, 1.0), ior_in=1.5, ior_out=1.0),
     ], api.MATERIAL_DTYPE)
+    if rough:                                             # Oren-Nayar walls and blob (sigma in degrees)
+        mats[0]["sigma"], mats[1]["sigma"], mats[3]["sigma"] = 20.0, 35.0, 60.0
     si = sl.to_input()
     env = ((1.0, 1.0, 1.0), env_intensity, 3.5) if env_intensity is not None else None
     desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=env, samples_in_flight=samples_in_flight)

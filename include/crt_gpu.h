@@ -255,7 +255,7 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * shadow (crt_shadow_batch_dev) -> accumulate } x (max_depth + 1) -> add to the colour buffer.
  * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
  *   geometry  TRIANGLE, FLAT_TRIANGLE, RECTANGLE, SPHERE; DISK only with an EMISSIVE material;
- *   materials MATTE with sigma == 0 and no texture (Lambertian, materials.cpp:116-128), MIRROR (specular
+ *   materials MATTE without texture (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR (specular
  *             reflection, materials.cpp:129-136), TRANSPARENT (thin specular transmission, :137-141), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
  *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform).

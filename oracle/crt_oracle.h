@@ -78,6 +78,8 @@ void  oracle_trace_local_basis(const float* a, const float* normal, float* out);
 float oracle_trace_lambertian(const float* cd, const float* basis, const float* wo, const float* sample,
                               float* f_out, float* wi_out, float* f_eval);
 float oracle_trace_mirror(const float* cr, const float* basis, const float* wo, float* f_out, float* wi_out, int* flags);
+float oracle_trace_orennayar(const float* r, float sigma, const float* basis, const float* wo, const float* sample,
+                             const float* wi_eval, float* f_out, float* wi_out, float* f_eval);
 float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, const float* basis, const float* wo,
                                float* f_out, float* wi_out, int* flags);
 

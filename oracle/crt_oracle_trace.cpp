@@ -215,8 +215,45 @@ float calcFresnelDielectric(const vec3 normal, const vec3 wo, float etaT, float 
     return (r_parl * r_parl + r_perp * r_perp) / 2;
 }
 
-enum { LOBE_LAMBERTIAN = 0, LOBE_SPECULAR_REFLECTION = 1, LOBE_SPECULAR_TRANSMISSION = 2 };
-struct Lobe { int kind; float ior_in, ior_out; float rand_float; };   /* rand_float: the value SpecularTransmission_sample_f draws from rand() */
+/* util/math.h:13-36 */
+inline float sinTheta(const vec3 w) { return sqrtf(maxf((float)0, (float)1 - w[2] * w[2])); }
+inline float clampf(float x, float mn, float mx) { return (x < mn ? mn : (x > mx ? mx : x)); }
+inline float cosPhi(const vec3 w) { float sin_theta = sinTheta(w); return (sin_theta == 0) ? 1 : clampf(w[0] / sin_theta, -1.0f, 1.0f); }
+inline float sinPhi(const vec3 w) { float sin_theta = sinTheta(w); return (sin_theta == 0) ? 0 : clampf(w[1] / sin_theta, -1.0f, 1.0f); }
+
+/* OrenNayar_f, reflection.cpp:191-214 */
+void OrenNayar_f(vec3 f, const vec3 wi, const vec3 wo, const vec3 r, float a, float b)
+{
+    float sin_theta_i = sinTheta(wi);
+    float sin_theta_o = sinTheta(wo);
+    float max_cos = 0.0f;
+    if (sin_theta_i > 1e-4 && sin_theta_o > 1e-4) {
+        float sin_phi_i = sinPhi(wi), cos_phi_i = cosPhi(wi);
+        float sin_phi_o = sinPhi(wo), cos_phi_o = cosPhi(wo);
+        float d_cos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
+        max_cos = maxf((float)0, d_cos);
+    }
+    float sin_alpha, tan_beta;
+    if (fabsf(wi[2]) > fabsf(wo[2])) {
+        sin_alpha = sin_theta_o;
+        tan_beta = sin_theta_i / fabsf(wi[2]);
+    } else {
+        sin_alpha = sin_theta_i;
+        tan_beta = sin_theta_o / fabsf(wo[2]);
+    }
+    vec3_scale(f, r, (a + b * max_cos * sin_alpha * tan_beta) * INV_PI);
+}
+/* BSDF_addOrenNayar, reflection.cpp:823-830 */
+void orenNayarAB(float sigma, float* a, float* b)
+{
+    float sigma_rad = sigma / 180.0f * (float)PI;                  /* degToRad, util/math.h:65-68 */
+    float sigma2 = sigma_rad * sigma_rad;
+    *a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+    *b = 0.45f * sigma2 / (sigma2 + 0.09f);
+}
+
+enum { LOBE_LAMBERTIAN = 0, LOBE_SPECULAR_REFLECTION = 1, LOBE_SPECULAR_TRANSMISSION = 2, LOBE_ORENNAYAR = 3 };
+struct Lobe { int kind; float ior_in, ior_out; float rand_float; float a, b; };   /* rand_float: the value SpecularTransmission_sample_f draws from rand() */
 
 /* BSDF_sample_f with num_bxdf == 1 */
 float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr, const Lobe& lobe)
@@ -251,6 +288,13 @@ float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const ve
             vec3_scale(f, f, (eta * eta) / fabsf(wi_local[2]));
             pdf = 1.0f - kr;
         }
+    } else if (lobe.kind == LOBE_ORENNAYAR) {                      /* OrenNayar_sample_f, reflection.cpp:221-232 */
+        vec3 tmp_wo;
+        vec3_copy(tmp_wo, wo_local);
+        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
+        mapSampleToHemisphere(wi_local, sample);
+        pdf = cosHemispherePdf(wi_local, tmp_wo);
+        OrenNayar_f(f, wi_local, wo_local, sr->cd, lobe.a, lobe.b);
     } else {                                                       /* Lambertian_sample_f */
         vec3 tmp_wo;
         vec3_copy(tmp_wo, wo_local);
@@ -332,10 +376,17 @@ bool estimateDirect(const Setup& S, vec3 L, const vec2 light_sample, const Shade
     if (vec3_dot(sample_to_hit_point, sample_normal) > 0.0f || vec3_dot(sample_to_hit_point, sr->normal) < 0.0f) return false;
     vec3 f;
     if (light_pdf > 0.0f && !vec3_equal(Li, BLACK)) {
-        /* BSDF_f: BLACK + Lambertian_f */
-        vec3 cur_f;
-        vec3_copy(cur_f, sr->cd);
-        vec3_scale(cur_f, cur_f, INV_PI);
+        /* BSDF_f: BLACK + Lambertian_f / OrenNayar_f.  BSDF_f hands the lobe the WORLD-space wi, wo
+         * (reflection.cpp:731), which only Oren-Nayar notices */
+        vec3 cur_f = {0.0f, 0.0f, 0.0f};
+        if (sr->mat->type == CRT_MAT_MATTE && sr->mat->sigma != 0.0f) {
+            float a, b;
+            orenNayarAB(sr->mat->sigma, &a, &b);
+            OrenNayar_f(cur_f, wi, sr->wo, sr->cd, a, b);
+        } else {
+            vec3_copy(cur_f, sr->cd);
+            vec3_scale(cur_f, cur_f, INV_PI);
+        }
         vec3_copy(f, BLACK);
         vec3_add(f, f, cur_f);
         vec3_scale(f, f, fabsf(vec3_dot(sr->normal, wi)));
@@ -429,7 +480,8 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         vec3 wo, wi, f;
         vec3_negate(wo, ray.d);
         vec2 sample = { rng(dim0 + 4), rng(dim0 + 5) };
-        Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f };
+        Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
+        if (sr.mat->type == CRT_MAT_MATTE && sr.mat->sigma != 0.0f) { lobe.kind = LOBE_ORENNAYAR; orenNayarAB(sr.mat->sigma, &lobe.a, &lobe.b); }
         if (sr.mat->type == CRT_MAT_MIRROR) lobe.kind = LOBE_SPECULAR_REFLECTION;
         if (sr.mat->type == CRT_MAT_TRANSPARENT) {
             lobe.kind = LOBE_SPECULAR_TRANSMISSION; lobe.ior_in = sr.mat->ior_in; lobe.ior_out = sr.mat->ior_out;
@@ -575,7 +627,7 @@ float oracle_trace_lambertian(const float* cd, const float* basis, const float* 
     vec3_copy(sr.cd, cd);
     vec3 wi = {0.0f, 0.0f, 0.0f};
     int flags = 0;
-    const Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f };
+    const Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
     float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, lobe);
     vec3_copy(wi_out, wi);
     vec3 cur_f;                                                    /* BSDF_f as estimateDirect uses it */
@@ -593,9 +645,28 @@ float oracle_trace_mirror(const float* cr, const float* basis, const float* wo, 
     vec3_copy(sr.cd, cr);
     vec3 wi = {0.0f, 0.0f, 0.0f};
     const vec2 sample = {0.5f, 0.5f};
-    const Lobe lobe = { LOBE_SPECULAR_REFLECTION, 1.0f, 1.0f, 0.0f };
+    const Lobe lobe = { LOBE_SPECULAR_REFLECTION, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
     float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
     vec3_copy(wi_out, wi);
+    return pdf;
+}
+/* Oren-Nayar: BSDF_sample_f (tangent space) and BSDF_f evaluated for (wi_eval, wo) as given (the reference gives it world vectors) */
+float oracle_trace_orennayar(const float* r, float sigma, const float* basis, const float* wo, const float* sample,
+                             const float* wi_eval, float* f_out, float* wi_out, float* f_eval)
+{
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
+    vec3_copy(sr.cd, r);
+    Lobe lobe = { LOBE_ORENNAYAR, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
+    orenNayarAB(sigma, &lobe.a, &lobe.b);
+    vec3 wi = {0.0f, 0.0f, 0.0f};
+    int flags = 0;
+    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, lobe);
+    vec3_copy(wi_out, wi);
+    vec3 cur_f;
+    OrenNayar_f(cur_f, wi_eval, wo, r, lobe.a, lobe.b);
+    vec3_copy(f_eval, BLACK);
+    vec3_add(f_eval, f_eval, cur_f);
     return pdf;
 }
 float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, const float* basis, const float* wo,
@@ -605,7 +676,7 @@ float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, co
     vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
     vec3 wi = {0.0f, 0.0f, 0.0f};
     const vec2 sample = {0.5f, 0.5f};
-    const Lobe lobe = { LOBE_SPECULAR_TRANSMISSION, ior_in, ior_out, rand_float };
+    const Lobe lobe = { LOBE_SPECULAR_TRANSMISSION, ior_in, ior_out, rand_float, 0.0f, 0.0f };
     float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
     vec3_copy(wi_out, wi);
     return pdf;

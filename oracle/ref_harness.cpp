@@ -546,6 +546,29 @@ REF_API float ref_mirror_bsdf(const float* cr, const float* basis, const float* 
     return pdf;
 }
 
+/* BSDF with one OrenNayar lobe (BSDF_addOrenNayar, MATTE with sigma != 0): BSDF_sample_f, and BSDF_f for (wi_eval, wo) */
+REF_API float ref_orennayar_bsdf(const float* rr, float sigma, const float* basis, const float* wo, const float* sample,
+                                 const float* wi_eval, float* f_out, float* wi_out, float* f_eval)
+{
+    static bool pool = initBSDFMem(1, 4);
+    (void)pool;
+    BSDF bsdf;
+    bsdf.num_bxdf = 0;
+    memcpy(bsdf.tangent, basis, 12); memcpy(bsdf.binormal, basis + 3, 12); memcpy(bsdf.normal, basis + 6, 12);
+    vec3 c = { rr[0], rr[1], rr[2] };
+    BSDF_addOrenNayar(&bsdf, c, sigma);
+    vec3 f = { 0, 0, 0 }, wi = { 0, 0, 0 }, w = { wo[0], wo[1], wo[2] }, we = { wi_eval[0], wi_eval[1], wi_eval[2] };
+    vec2 smp = { sample[0], sample[1] };
+    BxDFFlags flags = BSDF_NONE;
+    float pdf = BSDF_sample_f(f, wi, &flags, w, smp, &bsdf);
+    memcpy(f_out, f, 12); memcpy(wi_out, wi, 12);
+    vec3 fe = { 0, 0, 0 };
+    BSDF_f(fe, we, w, &bsdf, (BxDFFlags)(BSDF_SPECULAR | BSDF_GLOSSY));
+    memcpy(f_eval, fe, 12);
+    BSDF_freeBxDFs(&bsdf);
+    return pdf;
+}
+
 /* BSDF with one SpecularTransmission lobe (what computeScatteringFunc builds for TRANSPARENT).  The lobe draws
  * from libc rand(); srand(seed) first so that the caller knows the value. */
 REF_API float ref_transparent_bsdf(float ior_in, float ior_out, unsigned seed, const float* basis, const float* wo,

@@ -85,6 +85,8 @@ def _load_oracle(path):
         L.oracle_trace_lambertian.restype = C.c_float
         L.oracle_trace_mirror.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.oracle_trace_mirror.restype = C.c_float
+        L.oracle_trace_orennayar.argtypes = [vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+        L.oracle_trace_orennayar.restype = C.c_float
         L.oracle_trace_transparent.argtypes = [C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.oracle_trace_transparent.restype = C.c_float
     return L
@@ -133,6 +135,8 @@ def ref():
         L.ref_lambertian_bsdf.restype = C.c_float
         L.ref_mirror_bsdf.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.ref_mirror_bsdf.restype = C.c_float
+        L.ref_orennayar_bsdf.argtypes = [vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+        L.ref_orennayar_bsdf.restype = C.c_float
         L.ref_transparent_bsdf.argtypes = [C.c_float, C.c_float, C.c_uint, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.ref_transparent_bsdf.restype = C.c_float
         _ref = L

@@ -140,3 +140,29 @@ def test_transparent_bsdf():
             assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
         n_reflect += int(np.dot(wa, n) * np.dot(wo, n) > 0)
     assert 100 < n_reflect < 3900
+
+
+def test_orennayar_bsdf():
+    """MATTE with sigma != 0.  BSDF_f evaluates the lobe on the vectors it is given -- the reference gives it
+    world-space ones (reflection.cpp:731) -- so the evaluation is compared on arbitrary unit vectors."""
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(9)
+    for k in range(5000):
+        n = rng.standard_normal(3).astype(np.float32); n /= np.linalg.norm(n)
+        t = np.cross(n, rng.standard_normal(3)).astype(np.float32); t /= np.linalg.norm(t)
+        b = np.cross(n, t).astype(np.float32)
+        basis = np.concatenate([t, b, n]).astype(np.float32)
+        wo = rng.standard_normal(3).astype(np.float32); wo /= np.linalg.norm(wo)
+        we = rng.standard_normal(3).astype(np.float32); we /= np.linalg.norm(we)
+        if k % 25 == 0:
+            we = np.array([0.0, 0.0, 1.0], np.float32)          # sin_theta == 0 branch of cosPhi / sinPhi
+        rr = rng.random(3, dtype=np.float32)
+        sigma = np.float32(rng.random() * 60.0 + 0.5)
+        smp = rng.random(2, dtype=np.float32)
+        fa, wa, ea, fb, wb, eb = (np.zeros(3, np.float32) for _ in range(6))
+        pa = L.oracle_trace_orennayar(_p(rr), sigma, _p(basis), _p(wo), _p(smp), _p(we), _p(fa), _p(wa), _p(ea))
+        pb = R.ref_orennayar_bsdf(_p(rr), sigma, _p(basis), _p(wo), _p(smp), _p(we), _p(fb), _p(wb), _p(eb))
+        assert np.float32(pa) == np.float32(pb)
+        if pb != 0.0:
+            assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
+        assert ol.same_bits(ea, eb)
