@@ -95,11 +95,25 @@ MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity"
 assert MATERIAL_DTYPE.itemsize == 32
 
 
+class CrtMeshShading(C.Structure):
+    _fields_ = [("flat_normal", C.c_void_p), ("vertex_normals", C.c_void_p), ("vertex_tangents", C.c_void_p),
+                ("normal_mat_index", C.c_void_p), ("normal_mats", C.c_void_p), ("num_normal_mats", C.c_int32)]
+
+
+class CrtMesh(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tangents", C.c_void_p), ("indices", C.c_void_p),
+                ("num_vertices", C.c_int32), ("num_indices", C.c_int32)]
+
+
+class CrtMeshEntry(C.Structure):
+    _fields_ = [("scaling", C.c_float * 3), ("orientation", C.c_float * 3), ("location", C.c_float * 3), ("smooth", C.c_int32)]
+
+
 class CrtRenderDesc(C.Structure):
     _fields_ = [("objects", C.c_void_p), ("obj_material", C.c_void_p), ("materials", C.c_void_p), ("num_materials", C.c_int32),
                 ("has_env_light", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_float),
                 ("env_world_radius", C.c_float), ("max_depth", C.c_int32), ("samples_in_flight", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("mesh_shading", C.c_void_p)]
 
 
 class CrtRenderStats(C.Structure):
@@ -119,7 +133,7 @@ EXPORTS = [
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
     "crt_renderer_get_stats", "crt_renderer_read_dev", "crt_renderer_reset",
-    "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
+    "crt_bake_mesh", "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
 ]
 
 _lib = None
@@ -182,6 +196,7 @@ def lib():
     L.crt_renderer_get_stats.argtypes = [vp, C.POINTER(CrtRenderStats)]
     L.crt_renderer_read_dev.argtypes = [vp, vp, vp]
     L.crt_renderer_reset.argtypes = [vp, C.c_uint32]
+    L.crt_bake_mesh.argtypes = [C.POINTER(CrtMesh), C.POINTER(CrtMeshEntry), vp, vp, vp, vp, vp]
     L.crt_image_state_save.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int]
     L.crt_image_state_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.crt_image_state_free.argtypes = [vp]
@@ -306,7 +321,7 @@ class RenderDesc:
     """Materials, lights and limits of the restricted path tracer (crt_render_desc).  Keeps the numpy
     arrays alive; `.c` is the ctypes struct."""
 
-    def __init__(self, scene_input, obj_material, materials, max_depth, seed=0, env=None, samples_in_flight=0):
+    def __init__(self, scene_input, obj_material, materials, max_depth, seed=0, env=None, samples_in_flight=0, mesh_shading=None):
         self.scene_input = scene_input
         self._in = scene_input.c_struct()
         self.obj_material = np.ascontiguousarray(obj_material, dtype=np.int32)
@@ -325,7 +340,47 @@ class RenderDesc:
         c.max_depth = int(max_depth)
         c.samples_in_flight = int(samples_in_flight)
         c.seed = int(seed)
+        self.mesh_shading = mesh_shading                  # a MeshShading (keeps its arrays alive) or None
+        if mesh_shading is not None:
+            c.mesh_shading = C.addressof(mesh_shading.c)
         self.c = c
+
+
+class MeshShading:
+    """crt_mesh_shading: per-triangle shading arrays of FLAT / SMOOTH triangles (any may be None)."""
+
+    def __init__(self, flat_normal=None, vertex_normals=None, vertex_tangents=None, normal_mat_index=None, normal_mats=None):
+        f32 = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)      # noqa: E731
+        self.flat_normal, self.vertex_normals, self.vertex_tangents = f32(flat_normal), f32(vertex_normals), f32(vertex_tangents)
+        self.normal_mat_index = None if normal_mat_index is None else np.ascontiguousarray(normal_mat_index, np.int32)
+        self.normal_mats = f32(normal_mats)
+        c = CrtMeshShading()
+        c.flat_normal, c.vertex_normals, c.vertex_tangents = _ptr(self.flat_normal), _ptr(self.vertex_normals), _ptr(self.vertex_tangents)
+        c.normal_mat_index, c.normal_mats = _ptr(self.normal_mat_index), _ptr(self.normal_mats)
+        c.num_normal_mats = 0 if self.normal_mats is None else len(self.normal_mats.reshape(-1, 9))
+        self.c = c
+
+
+def bake_mesh(positions, indices, scaling, orientation, location, normals=None, tangents=None, L=None):
+    """crt_bake_mesh (generateMeshTriangles): -> dict(tri_verts [T, 9], flat_normal [T, 3], vertex_normals / vertex_tangents
+    [T, 9] or None, normal_mat [9])."""
+    L = L or lib()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.int32).reshape(-1)
+    nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    tan = None if tangents is None else np.ascontiguousarray(tangents, np.float32).reshape(-1, 3)
+    m = CrtMesh()
+    m.positions, m.normals, m.tangents, m.indices = _ptr(pos), _ptr(nrm), _ptr(tan), _ptr(idx)
+    m.num_vertices, m.num_indices = len(pos), len(idx)
+    e = CrtMeshEntry()
+    e.scaling, e.orientation, e.location = _f3(scaling), _f3(orientation), _f3(location)
+    T = len(idx) // 3
+    out = {"tri_verts": np.zeros((T, 9), np.float32), "flat_normal": np.zeros((T, 3), np.float32),
+           "vertex_normals": None if nrm is None else np.zeros((T, 9), np.float32),
+           "vertex_tangents": None if tan is None else np.zeros((T, 9), np.float32), "normal_mat": np.zeros(9, np.float32)}
+    _check(L.crt_bake_mesh(C.byref(m), C.byref(e), out["tri_verts"].ctypes.data, out["flat_normal"].ctypes.data,
+                           _ptr(out["vertex_normals"]), _ptr(out["vertex_tangents"]), out["normal_mat"].ctypes.data), "crt_bake_mesh")
+    return out
 
 
 def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0):

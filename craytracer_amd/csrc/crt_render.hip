@@ -132,7 +132,8 @@ enum { DIM_IMAGE = 0, DIM_LENS = 2, DIM_BOUNCE0 = 4, DIMS_PER_BOUNCE = 8,
 /* per-object shading record, indexed by insertion id (crt_hit.obj) */
 struct ShadeObj {
     int32_t type, mat;
-    float p[14];      /* TRIANGLE / FLAT: normal[3] tangent[3] | RECTANGLE: normal[3] dpdu[3] point[3] | SPHERE: center[3] radius */
+    float p[14];      /* TRIANGLE / FLAT: normal[3] tangent[3] | RECTANGLE: normal[3] dpdu[3] point[3] | SPHERE: center[3] radius |
+                         SMOOTH: triangle index, normal_mat index (as int bits) */
 };
 enum { LIGHT_ENV = 0, LIGHT_AREA = 1 };
 struct LightRec {
@@ -143,6 +144,7 @@ struct LightRec {
 
 struct RenderDev {
     const ShadeObj* objs; const crt_material* mats; const LightRec* lights;
+    const float* vnormals; const float* vtangents; const float* normal_mats;      /* SMOOTH_TRIANGLE: crt_mesh_shading arrays */
     int32_t num_lights, has_env, max_depth;
     float env_color[3], env_intensity, env_world_radius;
     uint32_t seed_lo, seed_hi, npix;
@@ -250,6 +252,17 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 if (dot(wo, normal) < 0.0f) normal = neg(normal);
             } else if (so.type == CRT_FLAT_TRIANGLE) {            /* triangle.cpp:199-202: not flipped */
                 normal = v3p(so.p); dpdu = v3p(so.p + 3);
+            } else if (so.type == CRT_SMOOTH_TRIANGLE) {          /* rayIntersectSmoothTriangle, triangle.cpp:226-251 */
+                const size_t tri = (size_t)__float_as_int(so.p[0]);
+                const float* nm = rd.normal_mats + 9 * (size_t)__float_as_int(so.p[1]);
+                const float* vn = rd.vnormals + 9 * tri;
+                const float* vt = rd.vtangents + 9 * tri;
+                const float w0 = 1.0f - hit.beta - hit.gamma;
+                /* interpTriangleVec3, triangle.cpp:206-216 */
+                const V3 ni = normalize(add(add(scale(v3p(vn), w0), scale(v3p(vn + 3), hit.beta)), scale(v3p(vn + 6), hit.gamma)));
+                normal = normalize(v3(dot(v3p(nm), ni), dot(v3p(nm + 3), ni), dot(v3p(nm + 6), ni)));        /* mat3_mult_vec3 */
+                const V3 ti = normalize(add(add(scale(v3p(vt), w0), scale(v3p(vt + 3), hit.beta)), scale(v3p(vt + 6), hit.gamma)));
+                dpdu = normalize(v3(dot(v3p(nm), ti), dot(v3p(nm + 3), ti), dot(v3p(nm + 6), ti)));
             } else if (so.type == CRT_RECTANGLE) {                /* rect.cpp:5-16,:34-46 */
                 const V3 rn = v3p(so.p);
                 const V3 disp = sub(v3p(so.p + 6), ro);
@@ -519,6 +532,8 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     }
     std::vector<ShadeObj> objs((size_t)in->num_obj);
     std::vector<LightRec> lights;
+    const crt_mesh_shading* ms = d->mesh_shading;
+    bool any_smooth = false;
     if (d->has_env_light) {                                       /* the scene file's ENV_LIGHT precedes the objects: light 0 */
         LightRec l; memset(&l, 0, sizeof l);
         l.kind = LIGHT_ENV; l.obj_type = -1;
@@ -536,13 +551,21 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         const crt_material& mt = d->materials[mi];
         ShadeObj so; memset(&so, 0, sizeof so);
         so.type = type; so.mat = mi;
-        if (type == CRT_TRIANGLE || type == CRT_FLAT_TRIANGLE) {
+        if (type == CRT_SMOOTH_TRIANGLE) {
+            if (ref < 0 || ref >= in->num_tris || !in->tri_verts) return CRT_E_INVALID;
+            if (!ms || !ms->vertex_normals || !ms->vertex_tangents || !ms->normal_mat_index || !ms->normal_mats) return CRT_E_UNSUPPORTED;
+            const int nmi = ms->normal_mat_index[ref];
+            if (nmi < 0 || nmi >= ms->num_normal_mats) return CRT_E_INVALID;
+            memcpy(so.p, &ref, 4); memcpy(so.p + 1, &nmi, 4);
+            any_smooth = true;
+        } else if (type == CRT_TRIANGLE || type == CRT_FLAT_TRIANGLE) {
             if (ref < 0 || ref >= in->num_tris || !in->tri_verts) return CRT_E_INVALID;
             const float* v = in->tri_verts + 9 * (size_t)ref;
             const float e1[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, e2[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
             float c[3];
             host_cross(c, e1, e2);
             host_normalize(so.p, c);                              /* calcTriangleNormal, triangle.cpp:4-12 */
+            if (type == CRT_FLAT_TRIANGLE && ms && ms->flat_normal) memcpy(so.p, ms->flat_normal + 3 * (size_t)ref, 12);   /* FlatTriangle.normal */
             host_normalize(so.p + 3, e1);                         /* dpdu: the reference leaves it unset for these two types; see DESIGN.md "N1" */
         } else if (type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) {
             if (ref < 0 || ref >= in->num_shapes || !in->shapes || in->shapes[ref].type != type) return CRT_E_INVALID;
@@ -596,7 +619,11 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     const size_t P = r->path_cap;
     RenderDev& rd = r->rd;
     ShadeObj* d_objs = 0; crt_material* d_mats = 0; LightRec* d_lights = 0;
+    float* d_vn = 0; float* d_vt = 0; float* d_nm = 0;
     rc = dev_alloc(r, &d_objs, objs.size());
+    if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_vn, 9 * (size_t)in->num_tris);
+    if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_vt, 9 * (size_t)in->num_tris);
+    if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_nm, 9 * (size_t)ms->num_normal_mats);
     if (rc == CRT_OK) rc = dev_alloc(r, &d_mats, (size_t)d->num_materials);
     if (rc == CRT_OK) rc = dev_alloc(r, &d_lights, lights.size());
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.beta, 3 * P);
@@ -623,11 +650,17 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     }
     ok = ok && hipMemcpy(d_mats, dev_mats.data(), dev_mats.size() * sizeof(crt_material), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice) == hipSuccess;
+    if (any_smooth) {
+        ok = ok && hipMemcpy(d_vn, ms->vertex_normals, 9 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_vt, ms->vertex_tangents, 9 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_nm, ms->normal_mats, 9 * (size_t)ms->num_normal_mats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(rd.counters, 0, 256) == hipSuccess;
     ok = ok && hipStreamCreate(&r->stream) == hipSuccess;
     if (!ok) { crt_renderer_destroy(r); return rc != CRT_OK ? rc : CRT_E_HIP; }
     rd.objs = d_objs; rd.mats = d_mats; rd.lights = d_lights;
+    rd.vnormals = d_vn; rd.vtangents = d_vt; rd.normal_mats = d_nm;
     rd.num_lights = (int32_t)lights.size();
     rd.has_env = d->has_env_light ? 1 : 0;
     rd.max_depth = d->max_depth;

@@ -369,6 +369,47 @@ def courtyard(n_copies, n_lat, n_lon, seed=5, room=10.0):
     return api.SceneInput(np.concatenate(parts, 0))
 
 
+def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, seed=11):
+    """A unit room of TRIANGLE walls with a sphere light and, baked through crt_bake_mesh (generateMeshTriangles) with a
+    non-uniform scale and a rotation, one indexed lat-long blob with per-vertex normals and tangents: SMOOTH_TRIANGLE
+    objects (smooth=True) or FLAT_TRIANGLE objects carrying FlatTriangle.normal.  Returns (SceneInput, RenderDesc, pos, look)."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0.08, math.pi - 0.08, n_lat + 1, dtype=np.float64)
+    ph = np.linspace(0.0, 2.0 * math.pi, n_lon, endpoint=False, dtype=np.float64)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    rad = 1.0 + 0.25 * np.sin(3 * T) * np.cos(4 * P) + 0.05 * rng.standard_normal(T.shape)
+    pos = np.stack([rad * np.sin(T) * np.cos(P), rad * np.cos(T), rad * np.sin(T) * np.sin(P)], -1).reshape(-1, 3).astype(F32)
+    nrm = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    tan = np.stack([-np.sin(P), np.zeros_like(P), np.cos(P)], -1).reshape(-1, 3).astype(F32)
+    idx = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d = a + n_lon, b + n_lon
+            idx += [a, c, b, b, c, d]
+    baked = api.bake_mesh(pos, idx, scaling=(0.22, 0.3, 0.2), orientation=(25.0, -15.0, 40.0), location=(0.5, 0.4, 0.45),
+                          normals=nrm.astype(F32), tangents=tan)
+    walls = room_tris((0, 0, 0), (1, 1, 1))
+    nw, nb = len(walls), len(baked["tri_verts"])
+    tris = np.concatenate([walls, baked["tri_verts"]], 0)
+    sl = ShapeList()
+    sl.sphere((0.8, 0.8, 0.3), 0.06)
+    shapes = np.array(sl.shapes, api.SHAPE_DTYPE)
+    obj_type = np.concatenate([np.full(nw, api.TRIANGLE), np.full(nb, api.SMOOTH_TRIANGLE if smooth else api.FLAT_TRIANGLE), [api.SPHERE]]).astype(np.int32)
+    obj_ref = np.concatenate([np.arange(nw + nb), [0]]).astype(np.int32)
+    si = api.SceneInput(tris, shapes, obj_type, obj_ref)
+    pad3, pad9 = np.zeros((nw, 3), F32), np.zeros((nw, 9), F32)
+    ms = api.MeshShading(flat_normal=np.concatenate([pad3, baked["flat_normal"]], 0),
+                         vertex_normals=np.concatenate([pad9, baked["vertex_normals"]], 0),
+                         vertex_tangents=np.concatenate([pad9, baked["vertex_tangents"]], 0),
+                         normal_mat_index=np.zeros(nw + nb, np.int32), normal_mats=baked["normal_mat"].reshape(1, 9))
+    mats = np.array([api.material(api.MAT_MATTE, (0.7, 0.7, 0.68)), api.material(api.MAT_MATTE, (0.6, 0.45, 0.25), sigma=25.0),
+                     api.material(api.MAT_EMISSIVE, (1.0, 0.9, 0.8), 60.0)], api.MATERIAL_DTYPE)
+    mat_of = [0] * nw + [1] * nb + [2]
+    desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=((0.6, 0.7, 1.0), 0.2, 3.5), mesh_shading=ms)
+    return si, desc, (0.5, 0.5, 0.98), (0.5, 0.42, 0.0)
+
+
 def courtyard_render(n_copies, n_lat, n_lon, seed=5, room=10.0, max_depth=5, rng_seed=1, env_intensity=1.0,
                      samples_in_flight=0):
     """The courtyard() stand-in as a render scene: TRIANGLE objects, open to the sky (the two ceiling

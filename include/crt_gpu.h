@@ -254,7 +254,8 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * "one bounce of every path per kernel": generate -> { extend (crt_intersect_batch_dev) -> shade ->
  * shadow (crt_shadow_batch_dev) -> accumulate } x (max_depth + 1) -> add to the colour buffer.
  * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
- *   geometry  TRIANGLE, FLAT_TRIANGLE, RECTANGLE, SPHERE; DISK only with an EMISSIVE material;
+ *   geometry  TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE (interpolated normals; needs crt_mesh_shading), RECTANGLE,
+ *             SPHERE; DISK only with an EMISSIVE material;
  *   materials MATTE without texture (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR (specular
  *             reflection, materials.cpp:129-136), TRANSPARENT (thin specular transmission, :137-141), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
@@ -269,6 +270,21 @@ enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_MIRROR = 2, CRT_MAT_TRANSPARENT =
  * (Transparent_s; the reference's `thin` model, reflection.cpp:243-269, ignores cf_in / cf_out).  EMISSIVE: Emissive.color, .intensity. */
 typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; float ior_in; float ior_out; } crt_material;
 
+/* Shading data of mesh triangles, per entry of crt_scene_input.tri_verts (optional).
+ *   FLAT_TRIANGLE   normal = flat_normal[tri] (FlatTriangle.normal: normal_mat * mesh face normal, normalised;
+ *                   buildscene.h:278-284).  Without it the normal is calcTriangleNormal of the baked vertices.
+ *   SMOOTH_TRIANGLE vertex_normals / vertex_tangents [tri][9]: mesh->normals / mesh->tangents of the three
+ *                   vertices, model space; normal_mats[normal_mat_index[tri]]: SmoothTriangle.normal_mat, row-major
+ *                   (rayIntersectSmoothTriangle, triangle.cpp:218-258).  Required for SMOOTH_TRIANGLE objects. */
+typedef struct crt_mesh_shading {
+    const float*   flat_normal;
+    const float*   vertex_normals;
+    const float*   vertex_tangents;
+    const int32_t* normal_mat_index;
+    const float*   normal_mats;
+    int32_t        num_normal_mats;
+} crt_mesh_shading;
+
 typedef struct crt_render_desc {
     const crt_scene_input* objects;      /* the insertion-order arrays the scene was built from */
     const int32_t*      obj_material;    /* [num_obj] index into materials[] (getObjectMatPtr, shapes.cpp) */
@@ -281,6 +297,7 @@ typedef struct crt_render_desc {
     int32_t             max_depth;       /* params.max_depth (config.txt) */
     uint32_t            samples_in_flight;/* samples per pixel traced concurrently; 0 = library picks (~2^22 paths) */
     uint64_t            seed;
+    const crt_mesh_shading* mesh_shading;/* NULL: no FLAT normals given, SMOOTH_TRIANGLE objects refused */
 } crt_render_desc;
 
 typedef struct crt_render_stats {
@@ -313,6 +330,24 @@ int  crt_renderer_reset(crt_renderer* r, uint32_t next_sample);
  * crt_renderer_render calls have completed): for reducing the buffers of several GPUs over RCCL. */
 int  crt_renderer_read_dev(crt_renderer* r, float* d_color_buffer, void* stream);
 int  crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out);
+
+/* ---- mesh baking (part of SURVEY 8f N2), host side ----------------------------------- */
+/* Mesh (mesh.h:11-22): the arrays generateMeshTriangles reads.  normals / tangents may be NULL. */
+typedef struct crt_mesh {
+    const float*   positions;            /* [num_vertices][3] */
+    const float*   normals;              /* [num_vertices][3] */
+    const float*   tangents;             /* [num_vertices][3] */
+    const int32_t* indices;              /* [num_indices], three per triangle */
+    int32_t        num_vertices, num_indices;
+} crt_mesh;
+/* MeshEntry (scene/scenedata.h): one OBJECT MESH entry of a scene file. orientation: Euler angles in degrees. */
+typedef struct crt_mesh_entry { float scaling[3]; float orientation[3]; float location[3]; int32_t smooth; } crt_mesh_entry;
+/* generateMeshTriangles (buildscene.h:214-311): num_indices/3 triangles, vertices scaled, rotated (eulerAngToMat3,
+ * util/math.cpp:65-78), translated.  Outputs, each sized for num_indices/3 triangles, any but tri_verts may be NULL:
+ * tri_verts [T][9] (crt_scene_input.tri_verts), flat_normal [T][3], vertex_normals / vertex_tangents [T][9]
+ * (crt_mesh_shading), normal_mat [9] = rotation * inverse scaling, row-major. */
+int  crt_bake_mesh(const crt_mesh* mesh, const crt_mesh_entry* entry, float* tri_verts, float* flat_normal,
+                   float* vertex_normals, float* vertex_tangents, float* normal_mat);
 
 /* ---- image state and 8-bit output, host side ---------------------- */
 /* saveImageState / readImageState (imagestate.h:5-43): "<num_samples>\n<width> <height>\n" followed by

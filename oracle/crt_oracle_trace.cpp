@@ -132,6 +132,23 @@ struct Rng {
     float operator()(uint32_t dim) const { return oracle_rng(seed, pixel, sample, dim); }
 };
 
+/* interpTriangleVec3, triangle.cpp:206-216; mat3_mult_vec3, util/mat.h:181-187 (row-major 3 x 3) */
+void interpTriangleVec3(vec3 out, const float beta, const float gamma, const vec3 v0, const vec3 v1, const vec3 v2)
+{
+    vec3 tmp;
+    vec3_scale(out, v0, 1.0f - beta - gamma);
+    vec3_scale(tmp, v1, beta);
+    vec3_add(out, out, tmp);
+    vec3_scale(tmp, v2, gamma);
+    vec3_add(out, out, tmp);
+    vec3_normalize(out, out);
+}
+void mat3_mult_vec3(vec3 r, const float* a, const vec3 b)
+{
+    vec3 t = { vec3_dot(a, b), vec3_dot(a + 3, b), vec3_dot(a + 6, b) };
+    vec3_copy(r, t);
+}
+
 /* ShadeRec tail of the intersector that produced `hit` */
 void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hit& hit)
 {
@@ -148,8 +165,21 @@ void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hi
         if (vec3_dot(sr->wo, sr->normal) < 0.0f) vec3_negate(sr->normal, sr->normal);
         vec3_copy(sr->dpdu, &S.tri_dpdu[3 * (size_t)ref]);
     } else if (type == CRT_FLAT_TRIANGLE) {
-        vec3_copy(sr->normal, &S.tri_normal[3 * (size_t)ref]);
+        const crt_mesh_shading* ms = S.d->mesh_shading;
+        vec3_copy(sr->normal, (ms && ms->flat_normal) ? ms->flat_normal + 3 * (size_t)ref : &S.tri_normal[3 * (size_t)ref]);
         vec3_copy(sr->dpdu, &S.tri_dpdu[3 * (size_t)ref]);
+    } else if (type == CRT_SMOOTH_TRIANGLE) {                      /* rayIntersectSmoothTriangle, triangle.cpp:226-251 */
+        const crt_mesh_shading* ms = S.d->mesh_shading;
+        const float* vn = ms->vertex_normals + 9 * (size_t)ref;
+        const float* vt = ms->vertex_tangents + 9 * (size_t)ref;
+        const float* nm = ms->normal_mats + 9 * (size_t)ms->normal_mat_index[ref];
+        vec3 tmp_normal, tmp, tangent;
+        interpTriangleVec3(tmp_normal, hit.beta, hit.gamma, vn, vn + 3, vn + 6);
+        mat3_mult_vec3(sr->normal, nm, tmp_normal);
+        vec3_normalize(sr->normal, sr->normal);
+        interpTriangleVec3(tmp, hit.beta, hit.gamma, vt, vt + 3, vt + 6);
+        mat3_mult_vec3(tangent, nm, tmp);
+        vec3_normalize(sr->dpdu, tangent);
     } else if (type == CRT_RECTANGLE) {
         const float* p = in->shapes[ref].p;                        /* point, width, height, normal */
         vec3 displacement, normal;
@@ -556,7 +586,10 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
     for (int i = 0; i < in->num_obj; i++) {                        /* initAreaLights */
         const int type = in->obj_type ? in->obj_type[i] : CRT_SMOOTH_TRIANGLE;
         const crt_material& mat = d->materials[d->obj_material[i]];
-        if (type != CRT_TRIANGLE && type != CRT_FLAT_TRIANGLE && type != CRT_RECTANGLE && type != CRT_SPHERE && type != CRT_DISK) return -1;
+        if (type == CRT_SMOOTH_TRIANGLE && !(d->mesh_shading && d->mesh_shading->vertex_normals && d->mesh_shading->vertex_tangents &&
+                                             d->mesh_shading->normal_mat_index && d->mesh_shading->normal_mats)) return -1;
+        if (type != CRT_TRIANGLE && type != CRT_FLAT_TRIANGLE && type != CRT_SMOOTH_TRIANGLE && type != CRT_RECTANGLE && type != CRT_SPHERE &&
+            type != CRT_DISK) return -1;
         if (type == CRT_DISK && mat.type != CRT_MAT_EMISSIVE) return -1;
         if ((type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) && mat.type == CRT_MAT_EMISSIVE) {
             Light l; l.kind = 1; l.obj_type = type; l.shape = in->shapes[in->obj_ref[i]].p;
@@ -605,6 +638,18 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
 }
 
 /* ---- the pieces tests/test_trace_pieces.py compares with the reference's own code (oracle/_ref) ---- */
+void oracle_trace_shade_rec_mesh(const crt_scene_input* in, const crt_mesh_shading* ms, int obj, const crt_ray* ray, float t,
+                                 float beta, float gamma, float* out)
+{
+    crt_render_desc d; memset(&d, 0, sizeof d);
+    d.objects = in; d.mesh_shading = ms;
+    Setup S; S.scene = 0; S.d = &d; S.seed = 0;
+    triangleSetup(&S, in);
+    crt_hit hit; hit.t = t; hit.obj = obj; hit.part = 0; hit.beta = beta; hit.gamma = gamma;
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    fillShadeRec(S, &sr, *ray, hit);
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+}
 void oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* ray, float t, float* out)
 {
     crt_render_desc d; memset(&d, 0, sizeof d);

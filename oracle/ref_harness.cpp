@@ -31,6 +31,8 @@
 #include "camera.h"
 #include "sampling.h"
 #include "reflection.h"
+#include "mesh.h"
+#include "util/mat.h"
 #include "util/util.h"
 #include "imagestate.h"
 
@@ -590,6 +592,72 @@ REF_API float ref_transparent_bsdf(float ior_in, float ior_out, unsigned seed, c
     *flags_out = (int)flags;
     BSDF_freeBxDFs(&bsdf);
     return pdf;
+}
+
+/* ---- mesh triangles: the reference's own smooth / flat intersectors and matrix helpers -------- */
+/* rayIntersectSmoothTriangle / rayIntersectFlatTriangle on one triangle of a three-vertex Mesh.  out = hit_point,
+ * normal, wo, dpdu; bg = beta, gamma of calcTriangleIntersect (recomputed here with the same function). */
+REF_API float ref_mesh_triangle_shade_rec(int smooth, const float* v, const float* vn, const float* vt, const float* flat_normal,
+                                          const float* normal_mat, const crt_ray* ray, float* out, float* bg, float dpdu_marker)
+{
+    Ray r; to_ray(&r, ray);
+    Mesh mesh; memset(&mesh, 0, sizeof mesh);
+    float normals[9], texcoords[6] = {0, 0, 0, 0, 0, 0};
+    vec3 tangents[3];
+    memcpy(normals, vn, sizeof normals); memcpy(tangents, vt, sizeof tangents);
+    mesh.normals = normals; mesh.tangents = tangents; mesh.texcoords = texcoords; mesh.num_texcoords = 0;
+    mat3 nm; memcpy(nm, normal_mat, sizeof nm);
+    ShadeRec sr;
+    vec3_assign(sr.dpdu, dpdu_marker, dpdu_marker, dpdu_marker);
+    vec2_assign(sr.uv, 0.0f, 0.0f);                                /* FlatTriangle wraps whatever uv holds (triangle.cpp:195-198) */
+    float t;
+    if (smooth) {
+        SmoothTriangle tri; memset(&tri, 0, sizeof tri);
+        tri.i0 = 0; tri.i1 = 1; tri.i2 = 2;
+        memcpy(tri.v0, v, 12); memcpy(tri.v1, v + 3, 12); memcpy(tri.v2, v + 6, 12);
+        tri.normal_mat = &nm; tri.mesh_ptr = &mesh; tri.mat = 0;
+        Material dummy; memset(&dummy, 0, sizeof dummy); tri.mat = &dummy;
+        t = rayIntersectSmoothTriangle(&sr, &tri, r);
+    } else {
+        FlatTriangle tri; memset(&tri, 0, sizeof tri);
+        tri.i0 = 0; tri.i1 = 1; tri.i2 = 2;
+        memcpy(tri.v0, v, 12); memcpy(tri.v1, v + 3, 12); memcpy(tri.v2, v + 6, 12);
+        memcpy(tri.normal, flat_normal, 12);
+        tri.mesh_ptr = &mesh;
+        Material dummy; memset(&dummy, 0, sizeof dummy); tri.mat = &dummy;
+        t = rayIntersectFlatTriangle(&sr, &tri, r);
+    }
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+    vec3 v0, v1, v2; memcpy(v0, v, 12); memcpy(v1, v + 3, 12); memcpy(v2, v + 6, 12);
+    calcTriangleIntersect(bg, bg + 1, v0, v1, v2, r);
+    return t;
+}
+/* The matrix steps of generateMeshTriangles (buildscene.h:216-225,:258-266,:278-284) through the reference's own
+ * eulerAngToMat3 / mat3_* / calcTriangleNormal: world vertex, normal_mat, FlatTriangle.normal of one model triangle. */
+REF_API void ref_bake_triangle(const float* scaling, const float* orientation, const float* location, const float* model_v,
+                               float* world_v, float* normal_mat_out, float* flat_normal_out)
+{
+    mat3 rotation, inv_scale_mat, normal_mat;
+    vec3 sc = { scaling[0], scaling[1], scaling[2] }, orient = { orientation[0], orientation[1], orientation[2] }, loc = { location[0], location[1], location[2] };
+    eulerAngToMat3(rotation, orient);
+    mat3_scale_inverse(inv_scale_mat, sc);
+    mat3_mult(normal_mat, rotation, inv_scale_mat);
+    memcpy(normal_mat_out, normal_mat, sizeof normal_mat);
+    vec3 mv[3];
+    for (int k = 0; k < 3; k++) {
+        vec3 vv = { model_v[3*k], model_v[3*k+1], model_v[3*k+2] };
+        vec3_copy(mv[k], vv);
+        vec3_mult(vv, sc, vv);
+        vec3 nv;
+        mat3_mult_vec3(nv, rotation, vv);
+        vec3_add(nv, loc, nv);
+        memcpy(world_v + 3*k, nv, 12);
+    }
+    vec3 face_normal, new_face_normal;
+    calcTriangleNormal(face_normal, mv[0], mv[1], mv[2]);
+    mat3_mult_vec3(new_face_normal, normal_mat, face_normal);
+    vec3_normalize(new_face_normal, new_face_normal);
+    memcpy(flat_normal_out, new_face_normal, 12);
 }
 
 /* ---- image state: the reference's own imagestate.h ------------------------- */

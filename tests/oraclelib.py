@@ -76,6 +76,9 @@ def _load_oracle(path):
                                     C.c_uint32, C.c_uint32, vp, C.c_int]
         L.oracle_trace_shade_rec.argtypes = [C.POINTER(api.CrtSceneInput), C.c_int, vp, C.c_float, vp]
         L.oracle_trace_shade_rec.restype = None
+        L.oracle_trace_shade_rec_mesh.argtypes = [C.POINTER(api.CrtSceneInput), C.POINTER(api.CrtMeshShading), C.c_int, vp, C.c_float,
+                                                  C.c_float, C.c_float, vp]
+        L.oracle_trace_shade_rec_mesh.restype = None
         for name in ("oracle_trace_disk", "oracle_trace_hemisphere"):
             getattr(L, name).argtypes = [vp, vp]
             getattr(L, name).restype = None
@@ -135,6 +138,10 @@ def ref():
         L.ref_lambertian_bsdf.restype = C.c_float
         L.ref_mirror_bsdf.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.ref_mirror_bsdf.restype = C.c_float
+        L.ref_mesh_triangle_shade_rec.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float]
+        L.ref_mesh_triangle_shade_rec.restype = C.c_float
+        L.ref_bake_triangle.argtypes = [vp] * 7
+        L.ref_bake_triangle.restype = None
         L.ref_orennayar_bsdf.argtypes = [vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
         L.ref_orennayar_bsdf.restype = C.c_float
         L.ref_transparent_bsdf.argtypes = [C.c_float, C.c_float, C.c_uint, vp, vp, vp, vp, C.POINTER(C.c_int)]

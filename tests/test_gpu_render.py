@@ -103,6 +103,18 @@ def test_oren_nayar_matte():
     assert not ol.same_bits(want, osc.render(smooth, cam, flm, 0, 4))
 
 
+@pytest.mark.parametrize("smooth", [True, False])
+def test_baked_mesh_with_interpolated_or_face_normals(smooth):
+    """A mesh baked by crt_bake_mesh into SMOOTH_TRIANGLE objects (normals and tangents interpolated with the hit's
+    barycentrics, through normal_mat) or FLAT_TRIANGLE objects (the transformed face normal, not turned towards the ray)."""
+    si, desc, pos, look = scenes.smooth_blob_room(smooth=smooth)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.1, 96, 80)
+    got, _, _ = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [4])
+    want = ol.OracleScene(si, api.ACCEL_BVH4).render(desc, cam, flm, 0, 4)
+    compare(got, want)
+
+
 def test_flat_triangles_keep_their_winding_normal():
     si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)

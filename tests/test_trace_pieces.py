@@ -166,3 +166,59 @@ def test_orennayar_bsdf():
         if pb != 0.0:
             assert ol.same_bits(fa, fb) and ol.same_bits(wa, wb)
         assert ol.same_bits(ea, eb)
+
+
+def test_bake_mesh_against_the_reference_matrix_steps():
+    """crt_bake_mesh (product, host) against generateMeshTriangles' steps run through the reference's own eulerAngToMat3 /
+    mat3_* / calcTriangleNormal: world vertices, normal_mat, FlatTriangle.normal -- bit for bit."""
+    R = ol.ref()
+    rng = np.random.default_rng(10)
+    for k in range(300):
+        pos = (rng.standard_normal((3, 3)) * (10.0 ** rng.integers(-2, 3))).astype(np.float32)
+        scaling = (0.1 + 3.0 * rng.random(3)).astype(np.float32)
+        orient = (rng.random(3) * 720.0 - 360.0).astype(np.float32)
+        loc = (rng.standard_normal(3) * 50.0).astype(np.float32)
+        if k % 10 == 0:
+            orient[:] = [0.0, 90.0, -180.0]
+        got = api.bake_mesh(pos, [0, 1, 2], scaling, orient, loc)
+        wv, nm, fn = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(3, np.float32)
+        R.ref_bake_triangle(_p(scaling), _p(orient), _p(loc), _p(pos), _p(wv), _p(nm), _p(fn))
+        assert ol.same_bits(got["tri_verts"][0], wv) and ol.same_bits(got["normal_mat"], nm) and ol.same_bits(got["flat_normal"][0], fn)
+
+
+def test_shade_rec_of_smooth_and_flat_mesh_triangles():
+    """fillShadeRec of the oracle for SMOOTH_TRIANGLE / FLAT_TRIANGLE against rayIntersectSmoothTriangle /
+    rayIntersectFlatTriangle themselves (a three-vertex Mesh built in the harness)."""
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(11)
+    marker = np.float32(-77.5)
+    n_hit = 0
+    for k in range(3000):
+        v = rng.standard_normal(9).astype(np.float32)
+        vn = rng.standard_normal((3, 3)).astype(np.float32); vn /= np.linalg.norm(vn, axis=1, keepdims=True)
+        vt = rng.standard_normal((3, 3)).astype(np.float32); vt /= np.linalg.norm(vt, axis=1, keepdims=True)
+        nm = (np.eye(3) + 0.4 * rng.standard_normal((3, 3))).astype(np.float32).reshape(9)
+        fn = rng.standard_normal(3).astype(np.float32); fn /= np.linalg.norm(fn)
+        centre = v.reshape(3, 3).mean(0)
+        o = (centre + rng.standard_normal(3) * 3.0).astype(np.float32)
+        target = (v.reshape(3, 3) * rng.dirichlet([1, 1, 1])[:, None]).sum(0)
+        d = (target - o); d = (d / np.linalg.norm(d)).astype(np.float32)
+        ray = np.concatenate([o, d]).astype(np.float32)
+        for smooth in (1, 0):
+            want, bg = np.zeros(12, np.float32), np.zeros(2, np.float32)
+            t = R.ref_mesh_triangle_shade_rec(smooth, _p(v), _p(vn), _p(vt), _p(fn), _p(nm), _p(ray), _p(want), _p(bg), marker)
+            if not t < 3.0e38:
+                continue
+            n_hit += 1
+            si = api.SceneInput(v.reshape(1, 9), None, np.array([api.SMOOTH_TRIANGLE if smooth else api.FLAT_TRIANGLE], np.int32),
+                                np.array([0], np.int32))
+            ms = api.MeshShading(fn.reshape(1, 3), vn.reshape(1, 9), vt.reshape(1, 9), np.zeros(1, np.int32), nm.reshape(1, 9))
+            cin = si.c_struct()
+            got = np.zeros(12, np.float32)
+            L.oracle_trace_shade_rec_mesh(C.byref(cin), C.byref(ms.c), 0, _p(ray), np.float32(t), bg[0], bg[1], _p(got))
+            assert ol.same_bits(got[:9], want[:9]), (smooth, got, want)
+            if smooth:
+                assert ol.same_bits(got[9:], want[9:])
+            else:
+                assert (want[9:] == marker).all()               # rayIntersectFlatTriangle never writes dpdu either
+    assert n_hit > 3000
