@@ -259,7 +259,8 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  *   materials MATTE without texture (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR (specular
  *             reflection, materials.cpp:129-136), TRANSPARENT (thin specular transmission, :137-141), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
- *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform).
+ *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform); no MeshLights
+ *             (EMISSIVE on FLAT / SMOOTH triangles is refused; on plain TRIANGLE objects it only emits).
  * Random numbers: the reference draws from per-thread sample tables (Sampler_getSample) and from libc
  * rand() (trace.h:371,:516), both dependent on thread scheduling.  Here every number is
  * crt_rng(seed, pixel, sample, dimension) (definition in DESIGN.md "N1"), so an image is a pure

@@ -196,6 +196,17 @@ def test_unsupported_scenes_are_refused():
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, om, desc.materials, 3), cam, flm)
     assert e.value.code == -1
+    s3, d3, _, _ = scenes.smooth_blob_room(8, 16)
+    om3 = d3.obj_material.copy()
+    om3[20] = 2                                                      # an EMISSIVE mesh triangle would be a MeshLight
+    b3 = api.BuiltScene(s3, api.ACCEL_BVH4)
+    sc3 = api.Scene(b3)
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(sc3, api.RenderDesc(s3, om3, d3.materials, 3, mesh_shading=d3.mesh_shading), cam, flm)
+    assert e.value.code == -4
+    with pytest.raises(api.CrtError) as e:                           # SMOOTH_TRIANGLE objects without their shading arrays
+        api.Renderer(sc3, api.RenderDesc(s3, d3.obj_material, d3.materials, 3), cam, flm)
+    assert e.value.code == -4
     s2 = scenes.analytic_scene()                                     # planes, instanced shapes
     b2 = api.BuiltScene(s2, api.ACCEL_BVH4)
     sc2 = api.Scene(b2)
