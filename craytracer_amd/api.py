@@ -105,6 +105,12 @@ class CrtMesh(C.Structure):
                 ("num_vertices", C.c_int32), ("num_indices", C.c_int32)]
 
 
+class CrtObjShape(C.Structure):
+    _fields_ = [("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
+                ("indices", C.POINTER(C.c_int32)), ("num_positions", C.c_int32), ("num_normals", C.c_int32),
+                ("num_texcoords", C.c_int32), ("num_indices", C.c_int32), ("mat_name", C.c_char * 64)]
+
+
 class CrtMeshEntry(C.Structure):
     _fields_ = [("scaling", C.c_float * 3), ("orientation", C.c_float * 3), ("location", C.c_float * 3), ("smooth", C.c_int32)]
 
@@ -131,9 +137,9 @@ EXPORTS = [
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
-    "crt_scene_device", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
+    "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
     "crt_renderer_get_stats", "crt_renderer_read_dev", "crt_renderer_reset",
-    "crt_bake_mesh", "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
+    "crt_bake_mesh", "crt_obj_load", "crt_obj_free", "crt_mesh_normals_tangents", "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
 ]
 
 _lib = None
@@ -188,6 +194,7 @@ def lib():
     L.crt_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.crt_scene_last_binning_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.crt_scene_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.crt_scene_num_objects.argtypes = [vp, C.POINTER(C.c_int)]
     L.crt_renderer_create.argtypes = [vp, C.POINTER(CrtRenderDesc), C.POINTER(CrtCamera), C.POINTER(CrtFilm), C.POINTER(vp)]
     L.crt_renderer_destroy.argtypes = [vp]
     L.crt_renderer_destroy.restype = None
@@ -197,6 +204,10 @@ def lib():
     L.crt_renderer_read_dev.argtypes = [vp, vp, vp]
     L.crt_renderer_reset.argtypes = [vp, C.c_uint32]
     L.crt_bake_mesh.argtypes = [C.POINTER(CrtMesh), C.POINTER(CrtMeshEntry), vp, vp, vp, vp, vp]
+    L.crt_obj_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CrtObjShape)), C.POINTER(C.c_int32)]
+    L.crt_obj_free.argtypes = [C.POINTER(CrtObjShape), C.c_int32]
+    L.crt_obj_free.restype = None
+    L.crt_mesh_normals_tangents.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
     L.crt_image_state_save.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int]
     L.crt_image_state_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.crt_image_state_free.argtypes = [vp]
@@ -381,6 +392,35 @@ def bake_mesh(positions, indices, scaling, orientation, location, normals=None, 
     _check(L.crt_bake_mesh(C.byref(m), C.byref(e), out["tri_verts"].ctypes.data, out["flat_normal"].ctypes.data,
                            _ptr(out["vertex_normals"]), _ptr(out["vertex_tangents"]), out["normal_mat"].ctypes.data), "crt_bake_mesh")
     return out
+
+
+def obj_load(path):
+    """crt_obj_load (loadOBJ): list of dicts with positions [V, 3], normals [Vn, 3], texcoords [Vt, 2], indices [T, 3], mat_name."""
+    shapes, n = C.POINTER(CrtObjShape)(), C.c_int32()
+    _check(lib().crt_obj_load(os.fsencode(path), C.byref(shapes), C.byref(n)), "crt_obj_load")
+    out = []
+    try:
+        for i in range(n.value):
+            s = shapes[i]
+            arr = lambda p, cnt, dt: np.ctypeslib.as_array(p, (cnt,)).astype(dt).copy() if cnt else np.zeros(0, dt)   # noqa: E731
+            out.append({"positions": arr(s.positions, s.num_positions, np.float32).reshape(-1, 3),
+                        "normals": arr(s.normals, s.num_normals, np.float32).reshape(-1, 3),
+                        "texcoords": arr(s.texcoords, s.num_texcoords, np.float32).reshape(-1, 2),
+                        "indices": arr(s.indices, s.num_indices, np.int32).reshape(-1, 3), "mat_name": s.mat_name.decode()})
+    finally:
+        lib().crt_obj_free(shapes, n)
+    return out
+
+
+def mesh_normals_tangents(positions, indices, normals=None):
+    """crt_mesh_normals_tangents: (normals [V, 3] -- given or generated as calcTriangleNormals does --, tangents [V, 3])."""
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.int32).reshape(-1)
+    nin = None if normals is None or len(normals) == 0 else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    nout, tout = np.zeros_like(pos), np.zeros_like(pos)
+    _check(lib().crt_mesh_normals_tangents(_ptr(pos), len(pos), _ptr(idx), len(idx), _ptr(nin), nout.ctypes.data, tout.ctypes.data),
+           "crt_mesh_normals_tangents")
+    return nout, tout
 
 
 def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0):

@@ -497,6 +497,13 @@ int crt_scene_device(const crt_scene* s, int* device)
     return CRT_OK;
 }
 
+int crt_scene_num_objects(const crt_scene* s, int* num_obj)
+{
+    if (!s || !num_obj) return CRT_E_INVALID;
+    *num_obj = s->dev.num_obj;
+    return CRT_OK;
+}
+
 int crt_scene_set_traverse_mode(crt_scene* s, int mode)
 {
     if (!s || mode < CRT_TRAVERSE_AUTO || mode > CRT_TRAVERSE_EXACT) return CRT_E_INVALID;

@@ -604,9 +604,11 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     for (const LightRec& l : lights) total_power += l.power;
     for (LightRec& l : lights) l.power /= total_power;            /* buildscene.h:921-922 */
 
-    int device = 0;
+    int device = 0, scene_objs = -1;
     int rc = crt_scene_device(scene, &device);
     if (rc != CRT_OK) return rc;
+    if ((rc = crt_scene_num_objects(scene, &scene_objs)) != CRT_OK) return rc;
+    if (scene_objs != in->num_obj) return CRT_E_INVALID;          /* hit ids index the per-object tables built above */
     crt_renderer* r = new (std::nothrow) crt_renderer();
     if (!r) return CRT_E_NOMEM;
     r->scene = scene; r->device = device; r->samples = 0; r->stream = 0;

@@ -310,9 +310,11 @@ typedef struct crt_render_stats {
 
 typedef struct crt_renderer crt_renderer;            /* opaque; owns device memory on the scene's GPU */
 
-/* GPU the scene lives on. */
+/* GPU the scene lives on; number of objects it was built from (hit ids are < this). */
 int  crt_scene_device(const crt_scene* s, int* device);
-/* The scene must have been built from desc->objects (hit ids index obj_material).  The renderer
+int  crt_scene_num_objects(const crt_scene* s, int* num_obj);
+/* The scene must have been built from desc->objects (hit ids index obj_material; a different object
+ * count is refused with CRT_E_INVALID).  The renderer
  * keeps a pointer to `scene` (destroy the renderer first); nothing else host-side is retained. */
 int  crt_renderer_create(crt_scene* scene, const crt_render_desc* desc, const crt_camera* cam, const crt_film* film,
                          crt_renderer** out);
@@ -349,6 +351,22 @@ typedef struct crt_mesh_entry { float scaling[3]; float orientation[3]; float lo
  * (crt_mesh_shading), normal_mat [9] = rotation * inverse scaling, row-major. */
 int  crt_bake_mesh(const crt_mesh* mesh, const crt_mesh_entry* entry, float* tri_verts, float* flat_normal,
                    float* vertex_normals, float* vertex_tangents, float* normal_mat);
+
+/* OBJShape (objloader/objloader.h:33-43): one group of an OBJ file as an indexed mesh.  num_* count floats / ints,
+ * as in the reference (num_positions = 3 * vertices). */
+typedef struct crt_obj_shape {
+    float*   positions; float* normals; float* texcoords; int32_t* indices;
+    int32_t  num_positions, num_normals, num_texcoords, num_indices;
+    char     mat_name[64];               /* the `usemtl` name in force (OBJ_NAME_LENGTH) */
+} crt_obj_shape;
+/* loadOBJ (objloader.h:738-939) without its MTL part: v / vn / vt / f records, fan triangulation, one vertex per
+ * distinct (v, vn, vt) triple numbered in order of first use, a shape per `g` / `usemtl` / `o` section. */
+int  crt_obj_load(const char* file_name, crt_obj_shape** shapes, int32_t* num_shapes);
+void crt_obj_free(crt_obj_shape* shapes, int32_t num_shapes);
+/* Per-vertex normals as calcTriangleNormals generates them when the shape has none (buildscene.h:58-98; normals_in
+ * != NULL: copied) and per-vertex tangents of calcTangentVec (buildscene.h:101-212).  Outputs [num_vertices][3]. */
+int  crt_mesh_normals_tangents(const float* positions, int32_t num_vertices, const int32_t* indices, int32_t num_indices,
+                               const float* normals_in, float* normals_out, float* tangents_out);
 
 /* ---- image state and 8-bit output, host side ---------------------- */
 /* saveImageState / readImageState (imagestate.h:5-43): "<num_samples>\n<width> <height>\n" followed by

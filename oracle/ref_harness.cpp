@@ -32,6 +32,7 @@
 #include "sampling.h"
 #include "reflection.h"
 #include "mesh.h"
+#include "objloader/objloader.h"
 #include "util/mat.h"
 #include "util/util.h"
 #include "imagestate.h"
@@ -658,6 +659,27 @@ REF_API void ref_bake_triangle(const float* scaling, const float* orientation, c
     mat3_mult_vec3(new_face_normal, normal_mat, face_normal);
     vec3_normalize(new_face_normal, new_face_normal);
     memcpy(flat_normal_out, new_face_normal, 12);
+}
+
+/* ---- OBJ files: the reference's own loadOBJ (objloader/objloader.h, implemented in mesh.cpp) -------- */
+static OBJShape* g_obj_shapes = 0; static OBJMaterial* g_obj_mats = 0; static int g_obj_num = 0, g_obj_num_mat = 0;
+REF_API int ref_obj_open(const char* file_name)
+{
+    g_obj_shapes = 0; g_obj_num = 0;
+    if (!loadOBJ(&g_obj_shapes, &g_obj_mats, &g_obj_num, &g_obj_num_mat, file_name)) return -1;
+    return g_obj_num;
+}
+REF_API void ref_obj_shape_sizes(int i, int* sizes)
+{
+    sizes[0] = g_obj_shapes[i].num_positions; sizes[1] = g_obj_shapes[i].num_normals;
+    sizes[2] = g_obj_shapes[i].num_texcoords; sizes[3] = g_obj_shapes[i].num_indices;
+}
+REF_API void ref_obj_shape_copy(int i, float* pos, float* nrm, float* tex, int* idx, char* mat_name)
+{
+    const OBJShape& s = g_obj_shapes[i];
+    memcpy(pos, s.positions, sizeof(float) * s.num_positions); memcpy(nrm, s.normals, sizeof(float) * s.num_normals);
+    memcpy(tex, s.texcoords, sizeof(float) * s.num_texcoords); memcpy(idx, s.indices, sizeof(int) * s.num_indices);
+    memcpy(mat_name, s.mat_name, OBJ_NAME_LENGTH);
 }
 
 /* ---- image state: the reference's own imagestate.h ------------------------- */

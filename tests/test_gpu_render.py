@@ -196,6 +196,10 @@ def test_unsupported_scenes_are_refused():
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, om, desc.materials, 3), cam, flm)
     assert e.value.code == -1
+    with pytest.raises(api.CrtError) as e:                           # a scene built from other objects
+        other = scenes.courtyard(1, 8, 8)
+        api.Renderer(api.Scene(api.BuiltScene(other, api.ACCEL_BVH4)), desc, cam, flm)
+    assert e.value.code == -1
     s3, d3, _, _ = scenes.smooth_blob_room(8, 16)
     om3 = d3.obj_material.copy()
     om3[20] = 2                                                      # an EMISSIVE mesh triangle would be a MeshLight
