@@ -137,22 +137,17 @@ def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device,
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
     flm = api.make_film(cam, 1.0, width, height)
     r = api.Renderer(sc, desc, cam, flm)
-    d_img = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
     r.render(1)                                           # warm-up pass
-    r.reset(rank * spp)                                   # rank k renders samples [k*spp, (k+1)*spp) of the one image
-    s0 = r.stats()
     barrier()
+    s0 = r.stats()
     t0 = time.perf_counter()
-    r.render(spp)
-    r.read_dev(d_img.data_ptr(), stream)
-    if world > 1:
-        dist.all_reduce(d_img)                            # RCCL: sum of the ranks' colour buffers
+    # rank k renders samples [k*spp, (k+1)*spp) of the one image; RCCL all-reduce of the colour buffers (world > 1)
+    d_img, total_spp = shard.render_sharded(r, spp, rank, world, device)
     barrier()
     dt = shard.max_over_ranks(time.perf_counter() - t0, device)
     s1 = r.stats()
     rays = (s1["rays_closest"] - s0["rays_closest"]) + (s1["rays_shadow"] - s0["rays_shadow"])
-    mean = float(d_img.mean().item()) / (spp * world)
+    mean = float(d_img.mean().item()) / total_spp
     res = {"metric": "samples/sec/pixel, wavefront path tracing (matte + env light), QBVH", "value": round(spp * world / dt, 3),
            "unit": "samples/s/pixel", "workload": "courtyard opened to a constant sky, %d triangles, %dx%d, max depth %d, %d spp per GPU timed"
            % (si.num_obj, width, height, depth, spp), "seconds": round(dt, 4),

@@ -47,3 +47,22 @@ def combine_radiance(buf, spp):
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         spp = int(c.item())
     return buf, spp
+
+
+def render_sharded(renderer, spp_per_rank, rank, world, device=None):
+    """Sample-range sharding of a render (the reference's unit of work is the sample pass, main.cpp:295): rank k of
+    `world` renders samples [k * S, (k + 1) * S) of the whole frame, then the colour buffers are summed over all ranks
+    (RCCL when `device` is a GPU and the process group is nccl; gloo sums the host copy).  Returns the combined
+    colour buffer as a torch tensor [h * w * 3] and the total sample count."""
+    renderer.reset(rank * spp_per_rank)
+    renderer.render(spp_per_rank)
+    n = renderer.width * renderer.height * 3
+    if device is not None and torch.device(device).type == "cuda" and (not dist.is_initialized() or dist.get_backend() == "nccl"):
+        buf = torch.zeros(n, dtype=torch.float32, device=device)
+        renderer.read_dev(buf.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+    else:
+        host, _ = renderer.read()
+        buf = torch.from_numpy(host.reshape(-1).copy())
+    buf, total = combine_radiance(buf, spp_per_rank)
+    return buf, total
