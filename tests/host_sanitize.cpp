@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <string>
+#include <cstring>
 
 static unsigned rng_state = 12345;
 static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return (rng_state >> 8) * (1.0f / 16777216.0f); }
@@ -26,6 +28,83 @@ static int build_all(const crt_scene_input& in, const char* what, bool grid_may_
         if (sum != (long long)in.num_obj * (in.num_obj - 1) / 2) { printf("%s accel %d: obj_id is not a permutation\n", what, accel); return 1; }
         crt_built_scene_destroy(b);
     }
+    return 0;
+}
+
+/* crt_obj.cpp, crt_mesh.cpp, crt_image.cpp on hostile inputs: every call must return a code, never read or write out of range */
+static int write_file(const char* path, const std::string& text)
+{
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return 1;
+    fwrite(text.data(), 1, text.size(), fp);
+    fclose(fp);
+    return 0;
+}
+static int obj_and_mesh_checks()
+{
+    const char* path = "/tmp/crt_host_sanitize.obj";
+    const char* texts[] = {
+        "", "\n\n", "f 1 2 3\n", "v 1 2\nf 1 1 1\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3 4 5\n", "v 0 0 0\nf -5 -6 -7\n",
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/9/9 2/9/9 3/9/9\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//-1 2//-1 3//-9\n",
+        "v a b c\nv 1e999 -1e999 nan\nv 0 1 0\nf 1 2 3\nusemtl\nusemtl     \ng\no \nf 3 2 1\n",
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3      \t  \nf 1/ 2/ 3/\nf 1// 2// 3//\nf /1 /2 /3\n",
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 2147483647 2 3\nf -2147483648 2 3\nf 99999999999999999999 2 3\n",
+    };
+    for (const char* text : texts) {
+        if (write_file(path, text)) { printf("cannot write %s\n", path); return 1; }
+        crt_obj_shape* shapes = 0; int32_t n = -1;
+        const int rc = crt_obj_load(path, &shapes, &n);
+        if (rc == CRT_OK) {
+            for (int i = 0; i < n; i++) {
+                const crt_obj_shape& s = shapes[i];
+                for (int k = 0; k < s.num_indices; k++) if (s.indices[k] < 0 || s.indices[k] * 3 + 2 >= s.num_positions) { printf("index out of range\n"); return 1; }
+                const int nv = s.num_positions / 3;
+                std::vector<float> nrm((size_t)nv * 3 + 1), tan((size_t)nv * 3 + 1);
+                if (crt_mesh_normals_tangents(s.positions, nv, s.indices, s.num_indices, 0, nrm.data(), tan.data()) != CRT_OK) { printf("normals_tangents\n"); return 1; }
+                crt_mesh mesh = { s.positions, nrm.data(), tan.data(), s.indices, nv, s.num_indices };
+                crt_mesh_entry e = { {1.0f, 2.0f, 0.5f}, {30.0f, 45.0f, 60.0f}, {1.0f, 2.0f, 3.0f}, 1 };
+                const int T = s.num_indices / 3;
+                std::vector<float> tv((size_t)T * 9 + 1), fn((size_t)T * 3 + 1), vn((size_t)T * 9 + 1), vt((size_t)T * 9 + 1);
+                float nm[9];
+                if (crt_bake_mesh(&mesh, &e, tv.data(), fn.data(), vn.data(), vt.data(), nm) != CRT_OK) { printf("bake\n"); return 1; }
+            }
+            crt_obj_free(shapes, n);
+        } else if (shapes != 0 || n != 0) { printf("outputs set on failure\n"); return 1; }
+    }
+    std::string big(5000, 'v');                                    /* a line longer than the reference's 1024-byte buffer */
+    if (write_file(path, big + "\nv 0 0 0\n")) return 1;
+    crt_obj_shape* shapes = 0; int32_t n = 0;
+    if (crt_obj_load(path, &shapes, &n) != CRT_OK) { printf("long line\n"); return 1; }
+    crt_obj_free(shapes, n);
+    if (crt_obj_load("/nonexistent/x.obj", &shapes, &n) != CRT_E_INVALID || crt_obj_load(0, &shapes, &n) != CRT_E_INVALID) { printf("obj error codes\n"); return 1; }
+    crt_obj_free(0, 0);
+    /* mesh argument checks */
+    float pos[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0}; int32_t bad_idx[3] = {0, 1, 3}; float out9[9], out3[3];
+    crt_mesh m = { pos, 0, 0, bad_idx, 3, 3 };
+    crt_mesh_entry e = { {1, 1, 1}, {0, 0, 0}, {0, 0, 0}, 0 };
+    if (crt_bake_mesh(&m, &e, out9, out3, 0, 0, 0) != CRT_E_INVALID) { printf("bake index check\n"); return 1; }
+    bad_idx[2] = 2;
+    if (crt_bake_mesh(&m, &e, out9, out3, out9, 0, 0) != CRT_E_INVALID) { printf("bake normals check\n"); return 1; }   /* normals asked for, mesh has none */
+    if (crt_bake_mesh(&m, &e, out9, out3, 0, 0, 0) != CRT_OK) { printf("bake ok case\n"); return 1; }
+    m.num_indices = 2;
+    if (crt_bake_mesh(&m, &e, out9, out3, 0, 0, 0) != CRT_E_INVALID) { printf("bake count check\n"); return 1; }
+    /* image state */
+    const char* ip = "/tmp/crt_host_sanitize.is";
+    const char* states[] = { "", "3", "3\n", "3\n2 2", "3\n2 2\n", "3\n-2 2\n", "x\n2 2\n", "3\n99999 99999\n", "3\n2 2\nabcdefgh" };
+    for (const char* st : states) {
+        if (write_file(ip, st)) return 1;
+        float* buf = 0; int ns = 0, w = 0, h = 0;
+        if (crt_image_state_load(ip, &buf, &ns, &w, &h) == CRT_OK) { printf("truncated image state accepted: '%s'\n", st); return 1; }
+        if (buf) { printf("buffer set on failure\n"); return 1; }
+    }
+    float cb[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 1e30f, -1.0f}; unsigned char img[12];
+    if (crt_image_state_save(ip, cb, 4, 2, 2) != CRT_OK) { printf("state save\n"); return 1; }
+    float* back = 0; int ns = 0, w = 0, h = 0;
+    if (crt_image_state_load(ip, &back, &ns, &w, &h) != CRT_OK || ns != 4 || w != 2 || h != 2 || memcmp(back, cb, sizeof cb)) { printf("state round trip\n"); return 1; }
+    crt_image_state_free(back);
+    if (crt_image_from_color_buffer(img, cb, 4, 4) != CRT_OK || crt_image_from_color_buffer(0, cb, 4, 4) != CRT_E_INVALID) { printf("tone map\n"); return 1; }
+    if (crt_ppm_write("/tmp/crt_host_sanitize.ppm", img, 2, 2) != CRT_OK || crt_ppm_write("/nonexistent/x.ppm", img, 2, 2) != CRT_E_INVALID) { printf("ppm\n"); return 1; }
+    remove(path); remove(ip); remove("/tmp/crt_host_sanitize.ppm");
     return 0;
 }
 
@@ -75,6 +154,7 @@ int main()
         if (crt_build_scene(&in, 1, &b) != CRT_E_INVALID) { printf("instance cycle check\n"); return 1; }
         crt_built_scene_destroy(0);
     }
+    if (obj_and_mesh_checks()) return 1;
     printf("host_sanitize ok\n");
     return 0;
 }
