@@ -204,6 +204,9 @@ void free_scene(crt_scene* s)
 /* ---- launch ------------------------------------------------------------------------- */
 
 const unsigned CRT_BIN_MIN_RAYS = 1u << 18;
+/* The walks saturate at 4 resident blocks (waves per SIMD) per CU: 691 / 936 / 1 090 / 1 092 Mrays/s at 2 / 3 / 4 / 5
+ * (closest hit, courtyard-10M); the any-hit walk, whose 16 KB stack would allow 7, runs 1 904 at 5 against 1 869 at 7. */
+const int CRT_MAX_BLOCKS_PER_CU = 5;
 
 template <class K>
 int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false)
@@ -211,6 +214,7 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CRT_BLOCK, 0));
     if (per_cu < 1) per_cu = 1;
+    if (per_cu > CRT_MAX_BLOCKS_PER_CU) per_cu = CRT_MAX_BLOCKS_PER_CU;
     unsigned blocks = (unsigned)(s->num_cus * per_cu);
     unsigned need = (la.n + CRT_BLOCK - 1) / CRT_BLOCK;
     if (blocks > need) blocks = need;
