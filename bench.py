@@ -132,7 +132,7 @@ def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device,
     import torch.distributed as dist
     width, height, depth, spp = 3840, 2160, 5, args.render_spp
     si, desc, pos, look = scenes.courtyard_render(n_copies, n_lat, n_lon, seed=5, max_depth=depth, rng_seed=1)
-    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=(args.builder == "sah"))
     sc = api.Scene(built, local_rank)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
     flm = api.make_film(cam, 1.0, width, height)
@@ -150,7 +150,7 @@ def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device,
     mean = float(d_img.mean().item()) / total_spp
     res = {"metric": "samples/sec/pixel, wavefront path tracing (matte + env light), QBVH", "value": round(spp * world / dt, 3),
            "unit": "samples/s/pixel", "workload": "courtyard opened to a constant sky, %d triangles, %dx%d, max depth %d, %d spp per GPU timed"
-           % (si.num_obj, width, height, depth, spp), "seconds": round(dt, 4),
+           % (si.num_obj, width, height, depth, spp), "builder": args.builder, "seconds": round(dt, 4),
            "mrays_per_s_all_queries_per_gpu": round(rays / (s1["ms_total"] - s0["ms_total"]) / 1e3, 1),
            "traversal_kernel_fraction": round(((s1["ms_extend"] - s0["ms_extend"]) + (s1["ms_shadow"] - s0["ms_shadow"]))
                                               / (s1["ms_total"] - s0["ms_total"]), 3),
@@ -193,11 +193,18 @@ def main():
                     help="the library's ray binning step (inside the timed region); off = arrival order")
     ap.add_argument("--accel", default="bvh4", choices=["bvh4", "bvh", "grid"],
                     help="bvh4 = the headline QBVH path; bvh / grid = the reference's other accelerators (extra lines)")
+    ap.add_argument("--builder", default=None, choices=["reference", "sah"],
+                    help="sah (default for bvh4) = CRT_BUILD_SAH: same QBVH node format and traversal, split planes by a surface-area "
+                         "heuristic; reference = the reference's median-split builder (bvh4.h:127-297), reported beside it by default")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
     args = ap.parse_args()
+    if args.builder is None:
+        args.builder = "sah" if args.accel == "bvh4" else "reference"
+    if args.builder == "sah" and args.accel != "bvh4":
+        raise SystemExit("--builder sah is a QBVH option")
 
     import torch
     from craytracer_amd import api, scenes, shard
@@ -219,7 +226,7 @@ def main():
     n_copies, n_lat, n_lon = WORKLOADS[args.workload]
     si = scenes.courtyard(n_copies, n_lat, n_lon, seed=5)
     accel = {"bvh4": api.ACCEL_BVH4, "bvh": api.ACCEL_BVH, "grid": api.ACCEL_GRID}[args.accel]
-    built = api.BuiltScene(si, accel)
+    built = api.BuiltScene(si, accel, sah=(args.builder == "sah"))
     sc = api.Scene(built, local_rank)
     sc.set_ray_binning(args.binning == "on")
     build_s = time.time() - t0
@@ -300,11 +307,12 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), %s, %d %s per GPU per step"
-                               % (args.workload, n_tris, {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel], n, "shadow rays from the incoherent hit points toward a ceiling light"
+                               % (args.workload, n_tris, {"bvh4": "QBVH (%s)" % ("SAH split planes" if args.builder == "sah" else "the reference's median split"),
+                                                            "bvh": "binary BVH", "grid": "uniform grid"}[args.accel], n, "shadow rays from the incoherent hit points toward a ceiling light"
                                   if shadow else "incoherent bounce-1..3 rays"),
                    "triangles": n_tris, "rays_per_gpu": n, "accel": args.accel.upper(), "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
                    if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),
-                   "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
+                   "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "builder": args.builder, "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
                    "scene_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
@@ -316,7 +324,8 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file)).get(args.workload + ("/shadow" if shadow else "")) if args.accel == "bvh4" else None
+            key = args.workload + ("@sah" if args.builder == "sah" else "") + ("/shadow" if shadow else "")
+            tr = json.load(open(traffic_file)).get(key) if args.accel == "bvh4" else None
             if tr and tr.get("rays") == n and args.binning == "on":
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 # measured fabric bytes (PMC, profiles/traffic.json) over the live kernel time: the
@@ -349,6 +358,37 @@ def main():
                           "value": round(n * world / s_best / 1e3, 1), "unit": "Mrays/s", "ms_per_launch": round(s_best, 4),
                           "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
         del s_rays, s_ld, s_t, s_occ
+
+    if not shadow and args.accel == "bvh4" and args.builder == "sah":
+        # the same rays through the reference's own median-split QBVH (what `value` was measured on until the SAH builder
+        # existed): rate, traversal statistics, and how many hit records differ between the two trees
+        try:
+            built_ref = api.BuiltScene(si, accel, sah=False)
+            sc_ref = api.Scene(built_ref, local_rank)
+            sc_ref.set_ray_binning(args.binning == "on")
+            r_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
+            sc_ref.enable_counters(True)
+            sc_ref.reset_counters()
+            sc_ref.intersect_dev(d_rays.data_ptr(), n, r_hits.data_ptr(), stream)
+            rc = sc_ref.counters()
+            sc_ref.enable_counters(False)
+            r_ms = []
+            for _ in range(4):
+                sc_ref.intersect_dev(d_rays.data_ptr(), n, r_hits.data_ptr(), stream)
+                r_ms.append(sc_ref.last_kernel_ms() + sc_ref.last_binning_ms())
+            r_best = shard.max_over_ranks(float(np.mean(r_ms[1:])), device)
+            differ = (r_hits != d_hits).any(dim=1)
+            ties = differ & (r_hits[:, 0] == d_hits[:, 0]) & (r_hits[:, 1] != d_hits[:, 1])      # bit-identical t, another object
+            out["reference_tree"] = {"metric": "Mrays/s closest-hit (incoherent), QBVH built as the reference builds it (median split)",
+                                     "value": round(n * world / r_best / 1e3, 1), "unit": "Mrays/s", "ms_per_launch": round(r_best, 4),
+                                     "nodes_per_ray": round(rc["nodes_visited"] / n, 3), "tris_per_ray": round(rc["prims_tested"] / n, 3),
+                                     "hit_records_differing_from_sah_tree": int(differ.sum().item()),
+                                     "of_which_exact_t_ties": int(ties.sum().item())}
+            del r_hits
+            sc_ref.close()
+            built_ref.close()
+        except Exception as e:
+            out["reference_tree"] = {"error": repr(e)[:300]}
 
     if not shadow and args.accel == "bvh4" and not args.no_render:
         # second half of BASELINE.json's metric: samples/sec/pixel of the wavefront path tracer on

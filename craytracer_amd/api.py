@@ -21,6 +21,7 @@ SPHERE, PLANE, RECTANGLE, AABOX, TRIANGLE, GENERICOPENCYLINDER, DISK, GENERICTOR
 ACCEL_NONE, ACCEL_GRID, ACCEL_BVH, ACCEL_BVH4 = range(4)
 ACCEL_NAMES = {"NONE": ACCEL_NONE, "GRID": ACCEL_GRID, "BVH": ACCEL_BVH, "BVH4": ACCEL_BVH4}
 TRAVERSE_AUTO, TRAVERSE_PRUNED, TRAVERSE_EXACT = range(3)
+BUILD_SAH = 1
 TRI_TYPES = (TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE)
 
 K_EPSILON = np.float32(0.000007)
@@ -129,7 +130,7 @@ class CrtRenderStats(C.Structure):
 
 # every symbol include/crt_gpu.h declares
 EXPORTS = [
-    "crt_build_scene", "crt_built_scene_desc", "crt_built_scene_destroy",
+    "crt_build_scene", "crt_build_scene_ex", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
     "crt_host_alloc", "crt_host_free",
@@ -164,6 +165,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.crt_build_scene.argtypes = [C.POINTER(CrtSceneInput), C.c_int, C.POINTER(vp)]
+    L.crt_build_scene_ex.argtypes = [C.POINTER(CrtSceneInput), C.c_int, C.c_int, C.POINTER(vp)]
     L.crt_built_scene_desc.argtypes = [vp]
     L.crt_built_scene_desc.restype = C.POINTER(CrtSceneDesc)
     L.crt_built_scene_destroy.argtypes = [vp]
@@ -523,11 +525,12 @@ def _view(ptr, n, dtype):
 class BuiltScene:
     """mvNonGridObjToStart + buildSceneAccel (scenedata.h:368, buildscene.h:698) on the host."""
 
-    def __init__(self, scene_input, accel):
+    def __init__(self, scene_input, accel, sah=False):
+        """sah=True: CRT_BUILD_SAH, the QBVH's split planes chosen by a surface-area heuristic (crt_build_scene_ex)."""
         self._h = C.c_void_p()
         self._input = scene_input            # keep arrays alive during the call only; build copies them
         cin = scene_input.c_struct()
-        _check(lib().crt_build_scene(C.byref(cin), int(accel), C.byref(self._h)), "crt_build_scene")
+        _check(lib().crt_build_scene_ex(C.byref(cin), int(accel), BUILD_SAH if sah else 0, C.byref(self._h)), "crt_build_scene_ex")
         self.desc = lib().crt_built_scene_desc(self._h).contents
         self.accel = int(accel)
 

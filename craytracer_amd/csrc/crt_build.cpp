@@ -267,6 +267,180 @@ void build4(Builder& B, NodeCountCache& ncc, int first, int count, int self, int
     }
 }
 
+
+/* ---- SAH QBVH (CRT_BUILD_SAH) ------------------------------------------------------------------
+ * Same node format, same leaf rule (a child with <= 4 objects is a leaf) and the same traversal as the
+ * reference's tree; only the choice of the three split planes of a node differs: binned surface-area
+ * heuristic over object centroids (32 bins per axis, all three axes) instead of the object median on
+ * the longest axis (bvh4.h:143-195).  Hits do not depend on the tree for objects that lie inside their
+ * boxes, so results are those of the reference's tree except for which of two exactly equal-t hits is
+ * found first.  The reference's builder balances by count, so a few scene-sized triangles (walls, a
+ * ground quad) bloat the boxes of every level they pass through; SAH puts them in their own subtrees.
+ * Depth is bounded for the traversal stack: near the limit the builder falls back to median splits. */
+const int SAH_BINS = 32;
+const int SAH_MAX_DEPTH = 20;                       /* levels; the pruned walk allows 21 (3 * depth + 1 <= 64) */
+
+inline float box_area(const Box& b)
+{
+    const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    return 2.0f * (dx * dy + dy * dz + dx * dz);
+}
+inline void box_grow(Box& a, const Box& b)
+{
+    for (int k = 0; k < 3; k++) { if (b.mn[k] < a.mn[k]) a.mn[k] = b.mn[k]; if (b.mx[k] > a.mx[k]) a.mx[k] = b.mx[k]; }
+}
+inline Box box_empty()
+{
+    Box b; for (int k = 0; k < 3; k++) { b.mn[k] = INFINITY; b.mx[k] = -INFINITY; } return b;
+}
+inline int levels_needed(int count)                 /* levels a median-split QBVH needs for `count` objects */
+{
+    int levels = 1;
+    long long cap = 16;                             /* one node: 4 children of <= 4 objects */
+    while (cap < count) { cap *= 4; levels++; }
+    return levels;
+}
+
+/* Reorders objects [first, first+count) so that the left part comes first; returns its size (0 < size < count),
+ * or 0 when no useful SAH plane exists.  *axis_out = split axis. */
+int sah_partition(Builder& B, int first, int count, int* axis_out)
+{
+    Box cb = box_empty();
+    for (int i = 0; i < count; i++) {
+        const Box& b = B.box[first + i];
+        for (int k = 0; k < 3; k++) {
+            const float c = (b.mn[k] + b.mx[k]) * 0.5f;
+            if (c < cb.mn[k]) cb.mn[k] = c;
+            if (c > cb.mx[k]) cb.mx[k] = c;
+        }
+    }
+    float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; axis++) {
+        const float ext = cb.mx[axis] - cb.mn[axis];
+        if (!(ext > 0.0f) || !(ext < INFINITY)) continue;
+        const float scale = (float)SAH_BINS / ext;
+        int cnt[SAH_BINS]; Box bb[SAH_BINS];
+        for (int k = 0; k < SAH_BINS; k++) { cnt[k] = 0; bb[k] = box_empty(); }
+        for (int i = 0; i < count; i++) {
+            const Box& b = B.box[first + i];
+            int k = (int)(((b.mn[axis] + b.mx[axis]) * 0.5f - cb.mn[axis]) * scale);
+            if (k < 0) k = 0; if (k >= SAH_BINS) k = SAH_BINS - 1;
+            cnt[k]++; box_grow(bb[k], b);
+        }
+        float right_area[SAH_BINS]; int right_cnt[SAH_BINS];
+        Box acc = box_empty(); int n = 0;
+        for (int k = SAH_BINS - 1; k > 0; k--) { box_grow(acc, bb[k]); n += cnt[k]; right_area[k] = box_area(acc); right_cnt[k] = n; }
+        acc = box_empty(); n = 0;
+        for (int k = 0; k < SAH_BINS - 1; k++) {
+            box_grow(acc, bb[k]); n += cnt[k];
+            if (n == 0 || right_cnt[k + 1] == 0) continue;
+            const float cost = box_area(acc) * (float)n + right_area[k + 1] * (float)right_cnt[k + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+        }
+    }
+    if (best_axis < 0) return 0;
+    /* stable partition by bin (keeps the builder deterministic) */
+    const float scale = (float)SAH_BINS / (cb.mx[best_axis] - cb.mn[best_axis]);
+    std::vector<int32_t> t(count), r(count), d(count);
+    std::vector<Box> bx(count);
+    int nl = 0;
+    int w = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < count; i++) {
+            const Box& b = B.box[first + i];
+            int k = (int)(((b.mn[best_axis] + b.mx[best_axis]) * 0.5f - cb.mn[best_axis]) * scale);
+            if (k < 0) k = 0; if (k >= SAH_BINS) k = SAH_BINS - 1;
+            if ((k <= best_bin) == (pass == 0)) {
+                const int s = first + i;
+                t[w] = B.type[s]; r[w] = B.ref[s]; d[w] = B.id[s]; bx[w] = B.box[s];
+                w++;
+                if (pass == 0) nl++;
+            }
+        }
+    for (int i = 0; i < count; i++) { B.type[first + i] = t[i]; B.ref[first + i] = r[i]; B.id[first + i] = d[i]; B.box[first + i] = bx[i]; }
+    *axis_out = best_axis;
+    return nl;
+}
+
+/* one binary split of [first, first+count): SAH when allowed and useful, else the reference's median split */
+int split_range(Builder& B, int first, int count, bool allow_sah, int* axis_out)
+{
+    if (count < 2) { *axis_out = 0; return count; }
+    if (allow_sah) {
+        const int nl = sah_partition(B, first, count, axis_out);
+        if (nl > 0 && nl < count) return nl;
+    }
+    const int axis = longest_axis(range_box(B, first, count));
+    sort_range(B, first, count, axis);
+    *axis_out = axis;
+    return count / 2;
+}
+
+/* Appends the subtree of objects [first, first+count) to `out` (indices relative to out's start); returns its root. */
+int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count, int depth)
+{
+    const int self = (int)out.size();
+    out.push_back(crt_bvh4_node());
+    /* SAH only while a median-split subtree for any part would still fit below the depth limit */
+    const bool allow_sah = depth + 1 + levels_needed(count) <= SAH_MAX_DEPTH;
+    int ax0 = 0, ax1 = 0, ax2 = 0;
+    const int mid = split_range(B, first, count, allow_sah, &ax0);
+    const int left = split_range(B, first, mid, allow_sah, &ax1);
+    const int right = mid + split_range(B, first + mid, count - mid, allow_sah, &ax2);
+    const int start[5] = { 0, left, mid, right, count };
+    crt_bvh4_node nd;
+    memset(&nd, 0, sizeof nd);
+    nd.axis = (uint8_t)ax2;
+    int child_cnt[4];
+    for (int c = 0; c < 4; c++) {
+        const int cnt = start[c + 1] - start[c];
+        child_cnt[c] = cnt;
+        if (cnt > 0) {
+            const Box b = range_box(B, first + start[c], cnt);
+            nd.bbox[c] = b.mn[0]; nd.bbox[4 + c] = b.mn[1]; nd.bbox[8 + c] = b.mn[2];
+            nd.bbox[12 + c] = b.mx[0]; nd.bbox[16 + c] = b.mx[1]; nd.bbox[20 + c] = b.mx[2];
+        } else {                                     /* empty child: a box no ray enters */
+            nd.bbox[c] = nd.bbox[4 + c] = nd.bbox[8 + c] = 1.0f;
+            nd.bbox[12 + c] = nd.bbox[16 + c] = nd.bbox[20 + c] = -1.0f;
+        }
+        if (cnt > 4) { nd.type[c] = -1; nd.child[c] = -1; }
+        else { nd.type[c] = (int8_t)cnt; nd.child[c] = first + start[c]; }
+    }
+    const bool fork = depth < 2 && B.max_threads > 1 && count > 65536;
+    if (fork) {
+        std::vector<std::vector<crt_bvh4_node> > sub(4);
+        std::vector<std::thread> th;
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+            std::vector<crt_bvh4_node>* dst = &sub[c];
+            const int f = first + start[c], cnt = child_cnt[c];
+            th.emplace_back([&B, dst, f, cnt, depth]() { build4_sah(B, *dst, f, cnt, depth + 1); });
+        }
+        for (auto& t : th) t.join();
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+            const int base = (int)out.size();
+            nd.child[c] = base;
+            for (crt_bvh4_node n : sub[c]) {
+                for (int k = 0; k < 4; k++) if (n.type[k] == -1) n.child[k] += base;
+                out.push_back(n);
+            }
+        }
+    } else {
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+            std::vector<crt_bvh4_node> sub;
+            build4_sah(B, sub, first + start[c], child_cnt[c], depth + 1);
+            const int base = (int)out.size();
+            nd.child[c] = base;
+            for (crt_bvh4_node n : sub) {
+                for (int k = 0; k < 4; k++) if (n.type[k] == -1) n.child[k] += base;
+                out.push_back(n);
+            }
+        }
+    }
+    out[self] = nd;
+    return self;
+}
+
 /* BVH_build, bvh.h:117-154: node box = union of the range, leaf at 1 object, median split. */
 void build2(Builder& B, int first, int count, int self, int depth)
 {
@@ -437,6 +611,13 @@ extern "C" {
 
 int crt_build_scene(const crt_scene_input* in, int accel, crt_built_scene** out)
 {
+    return crt_build_scene_ex(in, accel, 0, out);
+}
+
+int crt_build_scene_ex(const crt_scene_input* in, int accel, int flags, crt_built_scene** out)
+{
+    if (flags & ~CRT_BUILD_SAH) return CRT_E_INVALID;
+    if ((flags & CRT_BUILD_SAH) && accel != CRT_ACCEL_BVH4) return CRT_E_UNSUPPORTED;
     if (!in || !out || in->num_obj < 0 || in->num_tris < 0 || in->num_shapes < 0) return CRT_E_INVALID;
     if (accel < CRT_ACCEL_NONE || accel > CRT_ACCEL_BVH4) return CRT_E_INVALID;
     if (in->num_obj > 0 && in->obj_type && !in->obj_ref) return CRT_E_INVALID;
@@ -480,7 +661,9 @@ int crt_build_scene(const crt_scene_input* in, int accel, crt_built_scene** out)
         for (int i = 0; i < B.n; i++) object_box(in, B.type[i], B.ref[i], &B.box[i]);
         memset(&B.grid, 0, sizeof B.grid);
         int na = B.n - B.nng;
-        if (accel == CRT_ACCEL_BVH4 && na > 0) {
+        if (accel == CRT_ACCEL_BVH4 && na > 0 && (flags & CRT_BUILD_SAH)) {
+            build4_sah(B, B.nodes4, B.nng, na, 0);
+        } else if (accel == CRT_ACCEL_BVH4 && na > 0) {
             NodeCountCache ncc;
             long long total = na > 4 ? ncc.get(na) : 1;
             B.nodes4.resize((size_t)total);
