@@ -16,9 +16,9 @@ static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return (r
 /* grid_may_refuse: zero-volume or non-finite bounds have no grid resolution (CRT_E_INVALID) */
 static int build_all(const crt_scene_input& in, const char* what, bool grid_may_refuse = false)
 {
-    for (int accel = 0; accel < 4; accel++) {
+    for (int accel = 0; accel < 5; accel++) {           /* 4: the QBVH once more, built with CRT_BUILD_SAH */
         crt_built_scene* b = 0;
-        int rc = crt_build_scene(&in, accel, &b);
+        int rc = accel == 4 ? crt_build_scene_ex(&in, CRT_ACCEL_BVH4, CRT_BUILD_SAH, &b) : crt_build_scene(&in, accel, &b);
         if (rc == CRT_E_INVALID && accel == CRT_ACCEL_GRID && grid_may_refuse && b == 0) continue;
         if (rc != CRT_OK) { printf("%s accel %d: rc %d\n", what, accel, rc); return 1; }
         const crt_scene_desc* d = crt_built_scene_desc(b);

@@ -89,3 +89,67 @@ def test_invalid_inputs_are_rejected():
     bad[0] = 10 ** 6
     cin.obj_ref = bad.ctypes.data
     assert L.crt_build_scene(C.byref(cin), api.ACCEL_BVH4, C.byref(h)) == -1
+
+
+def _walk4(nodes, n_obj):
+    """(depth, objects seen in leaf order, list of (node, child) whose box does not contain its subtree)"""
+    seen, bad, depth = [], [], 0
+    stack = [(0, 1)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        nd = nodes[i]
+        for c in range(4):
+            if nd["type"][c] == -1:
+                assert i < nd["child"][c] < len(nodes)
+                stack.append((int(nd["child"][c]), d + 1))
+            else:
+                assert 0 <= nd["type"][c] <= 4
+                seen.extend(range(int(nd["child"][c]), int(nd["child"][c]) + int(nd["type"][c])))
+    return depth, seen
+
+
+@pytest.mark.parametrize("n", [0, 1, 4, 5, 17, 64, 65, 1000, 20000])
+def test_sah_tree_structure(n):
+    """CRT_BUILD_SAH: every object in exactly one leaf, leaves of at most 4, depth within the traversal stack, and the
+    oracle finds the same hits through it as through the reference's tree and as the linear loop (no accelerator)."""
+    tri = scenes.random_tris(n, seed=n + 1)
+    if n >= 64:                                           # a few scene-sized triangles among small ones: where SAH matters
+        big = scenes.room_tris((-3, -3, -3), (3, 3, 3))
+        tri = api.SceneInput(np.concatenate([tri.tri_verts, big], 0))
+    b = api.BuiltScene(tri, api.ACCEL_BVH4, sah=True)
+    ids = np.sort(b.obj_id)
+    assert (ids == np.arange(tri.num_obj)).all()
+    if tri.num_obj == 0:
+        return
+    depth, seen = _walk4(b.nodes4, tri.num_obj)
+    assert sorted(seen) == list(range(tri.num_obj)) and depth <= 20
+    lo, hi = scenes.scene_bounds(tri)
+    rays = scenes.random_rays(4000, lo, hi, seed=3)
+    h_sah = ol.OracleScene(tri, built=b).intersect(rays, mode=api.TRAVERSE_PRUNED)
+    h_ref = ol.OracleScene(tri, built=api.BuiltScene(tri, api.ACCEL_BVH4)).intersect(rays, mode=api.TRAVERSE_PRUNED)
+    h_lin = ol.OracleScene(tri, api.ACCEL_NONE).intersect(rays)
+    assert ol.same_bits(h_sah["t"], h_ref["t"]) and ol.same_bits(h_sah["t"], h_lin["t"])
+    differ = h_sah["obj"] != h_ref["obj"]
+    assert differ.mean() < 0.002                          # only exact-t ties may name another object
+
+
+def test_sah_tree_depth_is_bounded_on_adversarial_input():
+    """Geometric progression of sizes along one axis: an unbounded SAH build would make a chain; the builder falls back
+    to median splits near the stack limit."""
+    n = 3000
+    x = np.cumsum(1.5 ** (np.arange(n) % 40)).astype(np.float32)
+    v = np.zeros((n, 9), np.float32)
+    v[:, 0] = x; v[:, 3] = x + 0.1; v[:, 6] = x; v[:, 7] = 0.1; v[:, 4] = 0.05
+    tri = api.SceneInput(v)
+    b = api.BuiltScene(tri, api.ACCEL_BVH4, sah=True)
+    depth, seen = _walk4(b.nodes4, n)
+    assert depth <= 20 and sorted(seen) == list(range(n))
+
+
+def test_sah_flag_is_a_qbvh_option():
+    tri = scenes.random_tris(50, seed=2)
+    for accel in (api.ACCEL_NONE, api.ACCEL_GRID, api.ACCEL_BVH):
+        with pytest.raises(api.CrtError) as e:
+            api.BuiltScene(tri, accel, sah=True)
+        assert e.value.code == -4

@@ -28,9 +28,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CASES = {
-    # name: (scene factory, rays)
-    "buddha-1M": (lambda: scenes.buddha_like(512, 1024, seed=3), 1 << 22),
-    "courtyard-10M": (lambda: scenes.courtyard(640, 64, 128, seed=5), 1 << 24),
+    # name: (scene factory, rays, builder): the reference's median-split QBVH and the SAH-built one (CRT_BUILD_SAH)
+    "buddha-1M": (lambda: scenes.buddha_like(512, 1024, seed=3), 1 << 22, False),
+    "courtyard-10M": (lambda: scenes.courtyard(640, 64, 128, seed=5), 1 << 24, False),
+    "buddha-1M@sah": (lambda: scenes.buddha_like(512, 1024, seed=3), 1 << 22, True),
+    "courtyard-10M@sah": (lambda: scenes.courtyard(640, 64, 128, seed=5), 1 << 24, True),
 }
 TMAX = api.TMAX
 K_EPSILON = api.K_EPSILON
@@ -60,9 +62,9 @@ def tri_eval(tv, rays):
 def case(request):
     import torch
     import bench
-    make, n = CASES[request.param]
+    make, n, sah = CASES[request.param]
     si = make()
-    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=sah)
     sc = api.Scene(built, 0)
     dev = torch.device("cuda", 0)
     d_rays = bench.gen_incoherent_rays(sc, si, n, 0xC0FFEE, dev)
