@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--builder", default=None, choices=["reference", "sah"],
                     help="sah (default for bvh4) = CRT_BUILD_SAH: same QBVH node format and traversal, split planes by a surface-area "
                          "heuristic; reference = the reference's median-split builder (bvh4.h:127-297), reported beside it by default")
+    ap.add_argument("--no-reference-tree", action="store_true",
+                    help="skip the leg that repeats the batch on the reference's median-split tree (profiling runs: it launches "
+                         "the same kernel, so per-kernel profile averages would mix the two trees)")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
@@ -359,7 +362,7 @@ def main():
                           "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
         del s_rays, s_ld, s_t, s_occ
 
-    if not shadow and args.accel == "bvh4" and args.builder == "sah":
+    if not shadow and args.accel == "bvh4" and args.builder == "sah" and not args.no_reference_tree:
         # the same rays through the reference's own median-split QBVH (what `value` was measured on until the SAH builder
         # existed): rate, traversal statistics, and how many hit records differ between the two trees
         try:
