@@ -153,3 +153,52 @@ def test_sah_flag_is_a_qbvh_option():
         with pytest.raises(api.CrtError) as e:
             api.BuiltScene(tri, accel, sah=True)
         assert e.value.code == -4
+
+
+def _check_boxes(b, verts):
+    """every child box contains the vertices of every triangle below it, and an inner child's box is bit for bit the
+    union of the (non-empty) boxes of the node it points to"""
+    nodes = b.nodes4
+    order = b.obj_id
+    box = nodes["bbox"].reshape(len(nodes), 6, 4)           # rows minx miny minz maxx maxy maxz, columns = children
+
+    def below(i):                                           # (lo[3], hi[3]) of the vertices under node i, checking on the way
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for c in range(4):
+            ty, ch = int(nodes["type"][i][c]), int(nodes["child"][i][c])
+            if ty == -1:
+                lo, hi = below(ch)
+                sub = box[ch]
+                live = [k for k in range(4) if nodes["type"][ch][k] != 0]
+                assert ol.same_bits(sub[:3, live].min(1), box[i][:3, c]) and ol.same_bits(sub[3:, live].max(1), box[i][3:, c])
+            elif ty > 0:
+                v = verts[order[ch:ch + ty]].reshape(-1, 3)
+                lo, hi = v.min(0), v.max(0)
+            else:
+                assert (box[i][:3, c] > box[i][3:, c]).all()  # empty child: inverted box, no ray enters it
+                continue
+            assert (box[i][:3, c] <= lo).all() and (box[i][3:, c] >= hi).all()
+            lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+        return lo_all, hi_all
+
+    below(0)
+
+
+@pytest.mark.parametrize("n", [5, 300, 5000])
+def test_sah_boxes_bound_their_subtrees(n):
+    tri = scenes.random_tris(n, seed=n)
+    big = scenes.room_tris((-3, -3, -3), (3, 3, 3))
+    verts = np.concatenate([tri.tri_verts, big], 0)
+    si = api.SceneInput(verts)
+    _check_boxes(api.BuiltScene(si, api.ACCEL_BVH4, sah=True), verts.reshape(-1, 3, 3))
+    _check_boxes(api.BuiltScene(si, api.ACCEL_BVH4), verts.reshape(-1, 3, 3))
+
+
+def test_sah_coincident_triangles_fall_back_to_the_median():
+    """100 000 copies of one triangle: no plane separates the centroids; the builder must still end, within the depth
+    bound, with every copy in a leaf"""
+    n = 100000
+    v = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (n, 1))
+    b = api.BuiltScene(api.SceneInput(v), api.ACCEL_BVH4, sah=True)
+    depth, seen = _walk4(b.nodes4, n)
+    assert depth <= 20 and sorted(seen) == list(range(n))
