@@ -90,10 +90,21 @@ class CrtCounters(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
-MAT_MATTE, MAT_MIRROR, MAT_TRANSPARENT, MAT_EMISSIVE = 1, 2, 4, 8        # MatType, materials.h:8-18
+MAT_MATTE, MAT_MIRROR, MAT_TRANSPARENT, MAT_EMISSIVE, MAT_PLASTIC, MAT_GLASS, MAT_METAL = 1, 2, 4, 8, 16, 32, 64   # MatType, materials.h:8-18
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", (3,)), ("intensity", "<f4"), ("sigma", "<f4"),
-                           ("ior_in", "<f4"), ("ior_out", "<f4")])
-assert MATERIAL_DTYPE.itemsize == 32
+                           ("ior_in", "<f4"), ("ior_out", "<f4"), ("ks", "<f4", (3,)), ("k", "<f4", (3,)),
+                           ("uroughness", "<f4"), ("vroughness", "<f4")])
+assert MATERIAL_DTYPE.itemsize == 64
+# procMetalType's table (materials.cpp:5-20): name -> (eta, k)
+METALS = {
+    "GOLD": ((0.14282006, 0.37414363, 1.43944442), (3.90463543, 2.44763327, 2.13765264)),
+    "SILVER": ((0.154935181, 0.116475478, 0.138087392), (4.81810093, 3.11561656, 2.1424017)),
+    "BERYLLIUM": ((4.17617416, 3.1783011, 2.77819276), (3.82729554, 3.00373626, 2.86292768)),
+    "CHROMIUM": ((4.36040831, 2.9105196, 1.65118635), (5.19538164, 4.22238398, 3.74699736)),
+    "CESIUM": ((2.14034843, 1.69870293, 1.65889668), (0.0, 0.0, 0.0)),
+    "COPPER": ((0.19999069, 0.92208463, 1.09987593), (3.90463543, 2.44763327, 2.13765264)),
+    "MERCURY": ((2.39383841, 1.43696785, 0.907622635), (6.31419611, 4.36266136, 3.41453838)),
+}
 
 
 class CrtMeshShading(C.Structure):
@@ -425,7 +436,10 @@ def mesh_normals_tangents(positions, indices, normals=None):
     return nout, tout
 
 
-def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0):
+def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0, ks=(0.0, 0.0, 0.0), k=(0.0, 0.0, 0.0),
+             uroughness=0.0, vroughness=None):
+    """crt_material.  PLASTIC: color = kd, ks, uroughness = roughness.  GLASS: ior_in, ior_out, u/vroughness.
+    METAL: color = eta, k, u/vroughness (METALS holds the reference's table)."""
     m = np.zeros(1, MATERIAL_DTYPE)[0]
     m["type"] = type_
     m["color"] = np.asarray(color, np.float32)
@@ -433,6 +447,10 @@ def material(type_, color, intensity=0.0, sigma=0.0, ior_in=1.0, ior_out=1.0):
     m["sigma"] = sigma
     m["ior_in"] = ior_in
     m["ior_out"] = ior_out
+    m["ks"] = np.asarray(ks, np.float32)
+    m["k"] = np.asarray(k, np.float32)
+    m["uroughness"] = uroughness
+    m["vroughness"] = uroughness if vroughness is None else vroughness
     return m
 
 

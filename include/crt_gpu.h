@@ -273,10 +273,20 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * crt_rng(seed, pixel, sample, dimension) (definition in DESIGN.md "N1"), so an image is a pure
  * function of (scene, camera, seed, sample range).  Images therefore agree with the reference's in
  * distribution, not sample for sample. */
-enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_MIRROR = 2, CRT_MAT_TRANSPARENT = 4, CRT_MAT_EMISSIVE = 8 };     /* MatType, materials.h:8-18 */
-/* MATTE: color = Matte.color, sigma (materials.h Matte_s).  MIRROR: color = Mirror.color.  TRANSPARENT: ior_in, ior_out
- * (Transparent_s; the reference's `thin` model, reflection.cpp:243-269, ignores cf_in / cf_out).  EMISSIVE: Emissive.color, .intensity. */
-typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; float ior_in; float ior_out; } crt_material;
+enum crt_mat_type { CRT_MAT_MATTE = 1, CRT_MAT_MIRROR = 2, CRT_MAT_TRANSPARENT = 4, CRT_MAT_EMISSIVE = 8,
+                    CRT_MAT_PLASTIC = 16, CRT_MAT_GLASS = 32, CRT_MAT_METAL = 64 };                                /* MatType, materials.h:8-18 */
+/* The lobes computeScatteringFunc (materials.cpp:111-188) builds from each, textures aside:
+ *   MATTE        color = Matte.color, sigma: one Lambertian lobe, or one Oren-Nayar lobe when sigma != 0
+ *   MIRROR       color = Mirror.color: one SpecularReflection lobe
+ *   TRANSPARENT  ior_in, ior_out (the reference's `thin` SpecularTransmission lobe, reflection.cpp:243-269, ignores cf_in / cf_out)
+ *   EMISSIVE     color, intensity (Emissive_s)
+ *   PLASTIC      color = Plastic.kd, ks, uroughness = Plastic.roughness: FresnelBlendDiffuse + FresnelBlendSpecular (Beckmann, alpha = roughness)
+ *   GLASS        ior_in, ior_out, uroughness, vroughness (Glass_s): one MicrofacetFresnel lobe, white, Beckmann,
+ *                alpha = BeckmannRoughnessToAlpha(roughness) (microfacet.h:25-31)
+ *   METAL        color = Metal.eta, k = Metal.k, uroughness, vroughness (Metal_s; procMetalType's table, materials.cpp:5-20, is the
+ *                caller's): one MicrofacetReflection lobe with the conductor Fresnel term, Beckmann, alpha = roughness */
+typedef struct crt_material { int32_t type; float color[3]; float intensity; float sigma; float ior_in; float ior_out;
+                              float ks[3]; float k[3]; float uroughness; float vroughness; } crt_material;
 
 /* Shading data of mesh triangles, per entry of crt_scene_input.tri_verts (optional).
  *   FLAT_TRIANGLE   normal = flat_normal[tri] (FlatTriangle.normal: normal_mat * mesh face normal, normalised;

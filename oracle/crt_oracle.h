@@ -84,6 +84,11 @@ float oracle_trace_orennayar(const float* r, float sigma, const float* basis, co
                              const float* wi_eval, float* f_out, float* wi_out, float* f_eval);
 float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, const float* basis, const float* wo,
                                float* f_out, float* wi_out, int* flags);
+float oracle_trace_material_bsdf(const crt_material* mat, float rand_float, const float* basis, const float* wo, const float* sample,
+                                 const float* wi_eval, float* f_out, float* wi_out, int* flags_out, float* f_eval);
+void  oracle_trace_beckmann(float alphax, float alphay, const float* wo, const float* wi, const float* wh, const float* sample, float* out);
+void  oracle_trace_fresnel_conductor(const float* normal, const float* wo, const float* etaT, const float* etaI, const float* k, float* out);
+float oracle_trace_roughness_to_alpha(float roughness);
 
 #ifdef __cplusplus
 }

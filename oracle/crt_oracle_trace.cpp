@@ -120,11 +120,26 @@ struct Setup {
     std::vector<float> tri_normal, tri_dpdu;     /* per triangle */
     uint64_t seed;
 };
+enum { BSDF_NONE = 0, BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };   /* reflection.h:8-17 */
+enum { LAMBERTIAN, ORENNAYAR, SPECULAR_REFLECTION, SPECULAR_TRANSMISSION, MICROFACET_REFLECTION, MICROFACET_FRESNEL,
+       FRESNEL_BLEND, FRESNEL_BLEND_DIFFUSE, FRESNEL_BLEND_SPECULAR };                                                       /* BxDFType, reflection.h:19-30 */
+struct MicrofacetDistribution { float alphax, alphay; };       /* microfacet.h:10-16; every material uses BECKMANN (materials.cpp:161-185) */
+struct BxDF {                  /* the union of reflection.h's lobe structs */
+    int type;
+    vec3 color;                /* Lambertian.cd, OrenNayar.r, SpecularReflection.cr, Microfacet*.color, FresnelBlendDiffuse.kd */
+    vec3 ks;                   /* FresnelBlendDiffuse / FresnelBlendSpecular */
+    float a, b;                /* OrenNayar */
+    float ior_in, ior_out;
+    bool is_metal; vec3 k, etaI, etaT;
+    MicrofacetDistribution distrib;
+    float rand_float;          /* the value the lobe would draw from rand() (reflection.cpp:254,:419) */
+};
 struct ShadeRec {              /* util/shaderec.h, the fields this form reads */
     vec3 hit_point, normal, wo, dpdu;
     const crt_material* mat;
-    /* BSDF (reflection.h) with its single Lambertian lobe */
-    vec3 b_normal, b_tangent, b_binormal, cd;
+    /* BSDF (reflection.h:157-165) */
+    vec3 b_normal, b_tangent, b_binormal;
+    int num_bxdf; BxDF bxdfs[2];
 };
 
 struct Rng {
@@ -223,8 +238,6 @@ float cosHemispherePdf(const vec3 wi, const vec3 wo)
     return (wi[2] * wo[2] > 0.0f) ? fabsf(wi[2]) * INV_PI : 0.0f;
 }
 
-enum { BSDF_NONE = 0, BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };   /* reflection.h:8-17 */
-
 /* calcFresnelDielectric, reflection.cpp:52-76 */
 float calcFresnelDielectric(const vec3 normal, const vec3 wo, float etaT, float etaI)
 {
@@ -282,61 +295,500 @@ void orenNayarAB(float sigma, float* a, float* b)
     *b = 0.45f * sigma2 / (sigma2 + 0.09f);
 }
 
-enum { LOBE_LAMBERTIAN = 0, LOBE_SPECULAR_REFLECTION = 1, LOBE_SPECULAR_TRANSMISSION = 2, LOBE_ORENNAYAR = 3 };
-struct Lobe { int kind; float ior_in, ior_out; float rand_float; float a, b; };   /* rand_float: the value SpecularTransmission_sample_f draws from rand() */
+/* exp / log / tan / atan of the microfacet code.  The reference calls glibc's float routines (microfacet.cpp:19,:111,
+ * :121-122), which are within an ulp but not correctly rounded, and no GPU libm returns the same bits; product and oracle
+ * both take the double-precision function and round once.  Against the reference's own lobes that is a last-ulp
+ * difference in a small fraction of the calls (tests/test_trace_pieces.py states the bound and the observed count). */
+inline float r_expf(float x) { return (float)exp((double)x); }
+inline float r_logf(float x) { return (float)log((double)x); }
+inline float r_tanf(float x) { return (float)tan((double)x); }
+inline float r_atanf(float x) { return (float)atan((double)x); }
 
-/* BSDF_sample_f with num_bxdf == 1 */
-float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr, const Lobe& lobe)
+/* util/math.h:13-52 */
+inline float cosTheta(const vec3 w) { return w[2]; }
+inline float cos2Theta(const vec3 w) { return w[2] * w[2]; }
+inline float absCosTheta(const vec3 w) { return fabsf(w[2]); }
+inline float sin2Theta(const vec3 w) { return maxf((float)0, (float)1 - cos2Theta(w)); }
+inline float tanTheta(const vec3 w) { return sinTheta(w) / cosTheta(w); }
+inline float tan2Theta(const vec3 w) { return sin2Theta(w) / cos2Theta(w); }
+inline float cos2Phi(const vec3 w) { return cosPhi(w) * cosPhi(w); }
+inline float sin2Phi(const vec3 w) { return sinPhi(w) * sinPhi(w); }
+inline bool sameHemisphere(const vec3 a, const vec3 b) { return a[2] * b[2] > 0.0f; }
+
+/* microfacet.cpp:4-21, BECKMANN */
+float MicrofacetDistribution_D(const vec3 wh, const MicrofacetDistribution* distrib)
 {
-    const bool mirror = lobe.kind == LOBE_SPECULAR_REFLECTION;
-    *sampled_flags = mirror ? (BSDF_REFLECTION | BSDF_SPECULAR)                                        /* getBxDFFlagsFromType */
-                   : lobe.kind == LOBE_SPECULAR_TRANSMISSION ? (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR)   /* the lobe also reflects */
-                   : (BSDF_REFLECTION | BSDF_DIFFUSE);
+    float tan_2_theta = tan2Theta(wh);
+    if (isinf(tan_2_theta)) return 0.0f;
+    float cos_4_theta = cos2Theta(wh) * cos2Theta(wh);
+    return r_expf(-tan_2_theta * (cos2Phi(wh) / (distrib->alphax * distrib->alphax) +
+                                  sin2Phi(wh) / (distrib->alphay * distrib->alphay))) /
+        (PI * distrib->alphax * distrib->alphay * cos_4_theta);
+}
+/* microfacet.cpp:33-55 */
+float MicrofacetDistribution_Lambda(const vec3 w, const MicrofacetDistribution* distrib)
+{
+    float abs_tan_theta = fabsf(tanTheta(w));
+    if (isinf(abs_tan_theta)) return 0.0f;
+    float alpha = sqrtf(cos2Phi(w) * distrib->alphax * distrib->alphax + sin2Phi(w) * distrib->alphay * distrib->alphay);
+    float a = 1.0f / (alpha * abs_tan_theta);
+    if (a >= 1.6f) return 0.0f;
+    return (1.0f - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+}
+/* microfacet.cpp:72-75 */
+float MicrofacetDistribution_G(const vec3 wo, const vec3 wi, const MicrofacetDistribution* distrib)
+{
+    return 1.0f / (1.0f + MicrofacetDistribution_Lambda(wo, distrib) + MicrofacetDistribution_Lambda(wi, distrib));
+}
+/* microfacet.cpp:77-135; sphericalDirection, util/math.h:91-93 */
+void MicrofacetDistribution_sample_wh(vec3 wh, const vec3 wo, const vec2 sample, const MicrofacetDistribution* distrib)
+{
+    float tan_2_theta, phi;
+    if (distrib->alphax == distrib->alphay) {
+        float log_sample = r_logf(sample[0]);
+        if (isinf(log_sample)) log_sample = 0.0f;
+        tan_2_theta = -distrib->alphax * distrib->alphax * log_sample;
+        phi = sample[1] * 2.0f * PI;
+    } else {
+        float log_sample = r_logf(sample[0]);
+        if (isinf(log_sample)) log_sample = 0.0f;
+        phi = r_atanf(distrib->alphay / distrib->alphax * r_tanf(2.0f * PI * sample[1] + 0.5f * PI));
+        if (sample[1] > 0.5f) phi += PI;
+        float sin_phi = sinf(phi), cos_phi = cosf(phi);
+        float alphax2 = distrib->alphax * distrib->alphax;
+        float alphay2 = distrib->alphay * distrib->alphay;
+        tan_2_theta = -log_sample / (cos_phi * cos_phi / alphax2 + sin_phi * sin_phi / alphay2);
+    }
+    float cos_theta = 1.0f / sqrtf(1.0f + tan_2_theta);
+    float sin_theta = sqrtf(maxf(0.0f, 1.0f - cos_theta * cos_theta));
+    vec3_assign(wh, sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+    if (!sameHemisphere(wo, wh)) vec3_negate(wh, wh);
+}
+/* microfacet.cpp:137-140 */
+float MicrofacetDistribution_pdf(const vec3 wo, const vec3 wh, const MicrofacetDistribution* distrib)
+{
+    (void)wo;
+    return MicrofacetDistribution_D(wh, distrib) * absCosTheta(wh);
+}
+/* microfacet.h:25-31; runs once per material, on the host in the product too, so glibc's logf as in the reference */
+float BeckmannRoughnessToAlpha(float roughness)
+{
+    roughness = maxf(roughness, 1e-3);
+    float x = logf(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
+/* calcFresnelConductor, reflection.cpp:78-157 */
+void calcFresnelConductor(vec3 fresnel, const vec3 normal, const vec3 wo, const vec3 etaT, const vec3 etaI, const vec3 k)
+{
+    float cos_theta_i = vec3_dot(wo, normal);
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i;
+    float sin_theta_i_2 = 1.0f - cos_theta_i_2;
+    for (int c = 0; c < 3; c++) {                                  /* the vec3_* calls of the reference, per component */
+        float eta = etaT[c] / etaI[c];
+        float etaK = k[c] / etaI[c];
+        float eta2 = eta * eta;
+        float etaK2 = etaK * etaK;
+        float t0 = eta2 - etaK2;
+        t0 = t0 - sin_theta_i_2;
+        float t0_2 = t0 * t0;
+        float eta2_2 = eta2 * etaK2;
+        eta2_2 = eta2_2 * 4.0f;
+        float a2plusb2 = sqrtf(t0_2 + eta2_2);
+        float t1 = a2plusb2 + cos_theta_i_2;
+        float a = a2plusb2 + t0;
+        a = a * 0.5f;
+        a = sqrtf(a);
+        float t2 = a * (2.0f * cos_theta_i);
+        float rs = (t1 - t2) / (t1 + t2);
+        float t3 = a2plusb2 * cos_theta_i_2;
+        t3 = t3 + sin_theta_i_2 * sin_theta_i_2;
+        float t4 = t2 * sin_theta_i_2;
+        float rp = (t3 - t4) / (t3 + t4);
+        rp = rp * rs;
+        fresnel[c] = (rp + rs) * 0.5f;
+    }
+}
+
+/* util/ray.cpp:11-17,:42-59 */
+void calcReflectRayDir(vec3 reflect_dir, const vec3 normal, const vec3 incident_dir)
+{
+    float magnitude = -2.0f * vec3_dot(incident_dir, normal);
+    vec3 adjusted_normal;
+    vec3_scale(adjusted_normal, normal, magnitude);
+    vec3_add(reflect_dir, incident_dir, adjusted_normal);
+}
+bool refract(vec3 wi, const vec3 wo, const vec3 n, const float eta)
+{
+    float cos_theta_i = vec3_dot(n, wo);
+    float sin_2_theta_i = maxf(0.0f, 1.0f - cos_theta_i * cos_theta_i);
+    float sin_2_theta_t = eta * eta * sin_2_theta_i;
+    if (sin_2_theta_t >= 1.0f) return false;
+    float cos_theta_t = sqrtf(1.0f - sin_2_theta_t);
+    vec3 perp_comp, neg_wo;
+    vec3_negate(neg_wo, wo);
+    vec3_scale(perp_comp, neg_wo, eta);
+    float scale_factor = eta * cos_theta_i - cos_theta_t;
+    vec3 parallel_comp;
+    vec3_scale(parallel_comp, n, scale_factor);
+    vec3_add(wi, perp_comp, parallel_comp);
+    return true;
+}
+
+int getBxDFFlagsFromType(int type)                                 /* reflection.h:32-57 */
+{
+    switch (type) {
+    case LAMBERTIAN: case ORENNAYAR: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case SPECULAR_REFLECTION: return BSDF_REFLECTION | BSDF_SPECULAR;
+    case SPECULAR_TRANSMISSION: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+    case MICROFACET_REFLECTION: return BSDF_REFLECTION | BSDF_GLOSSY;
+    case MICROFACET_FRESNEL: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_GLOSSY;
+    case FRESNEL_BLEND: case FRESNEL_BLEND_DIFFUSE: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case FRESNEL_BLEND_SPECULAR: return BSDF_REFLECTION | BSDF_GLOSSY;
+    default: return BSDF_NONE;
+    }
+}
+
+/* MicrofacetReflection_f, reflection.cpp:297-327.  f is written only when the lobe has something to say. */
+void MicrofacetReflection_f(vec3 f, const vec3 wi, const vec3 wo, const BxDF* mf)
+{
+    float cos_theta_o = absCosTheta(wo), cos_theta_i = absCosTheta(wi);
+    vec3 wh;
+    vec3_add(wh, wi, wo);
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f) return;
+    if (wh[0] == 0.0f && wh[1] == 0.0f && wh[2] == 0.0f) return;
+    vec3_normalize(wh, wh);
+    vec3 fresnel_reflectance;
+    if (!mf->is_metal) {
+        float kr = 1.0f - calcFresnelDielectric(wh, wi, mf->ior_in, mf->ior_out);      /* as written there: 1 - kr */
+        vec3_assign(fresnel_reflectance, kr, kr, kr);
+    } else {
+        calcFresnelConductor(fresnel_reflectance, wh, wi, mf->etaT, mf->etaI, mf->k);
+    }
+    float scale_factor = MicrofacetDistribution_D(wh, &mf->distrib) * MicrofacetDistribution_G(wo, wi, &mf->distrib) /
+        (4.0f * cos_theta_i * cos_theta_o);
+    vec3_scale(f, mf->color, scale_factor);
+    vec3_mult(f, f, fresnel_reflectance);
+}
+/* reflection.cpp:329-344 */
+float MicrofacetReflection_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const BxDF* mr)
+{
+    if (wo[2] == 0.0f) return 0.0f;
+    vec3 wh;
+    MicrofacetDistribution_sample_wh(wh, wo, sample, &mr->distrib);
+    vec3 neg_wo;
+    vec3_negate(neg_wo, wo);
+    calcReflectRayDir(wi, wh, neg_wo);
+    if (!sameHemisphere(wo, wi)) return 0.0f;
+    MicrofacetReflection_f(f, wi, wo, mr);
+    return MicrofacetDistribution_pdf(wo, wh, &mr->distrib) / (4.0f * vec3_dot(wo, wh));
+}
+/* reflection.cpp:346-353 */
+float MicrofacetReflection_pdf(const vec3 wi, const vec3 wo, const BxDF* mr)
+{
+    if (!sameHemisphere(wi, wo)) return 0.0f;
+    vec3 wh;
+    vec3_add(wh, wo, wi);
+    vec3_normalize(wh, wh);
+    return MicrofacetDistribution_pdf(wo, wh, &mr->distrib) / (4.0f * vec3_dot(wo, wh));
+}
+/* reflection.cpp:356-387 */
+void MicrofacetFresnel_f(vec3 f, const vec3 wi, const vec3 wo, const BxDF* mt)
+{
+    if (sameHemisphere(wo, wi)) return;
+    float cos_theta_o = cosTheta(wo);
+    float cos_theta_i = cosTheta(wi);
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f) { vec3_copy(f, BLACK); return; }
+    float eta = cos_theta_o > 0.0f ? (mt->ior_in / mt->ior_out) : (mt->ior_out / mt->ior_in);
+    vec3 wh, scaled_wi;
+    vec3_scale(scaled_wi, wi, eta);
+    vec3_add(wh, wo, scaled_wi);
+    vec3_normalize(wh, wh);
+    if (wh[2] < 0.0f) vec3_negate(wh, wh);
+    float fresnel_reflectance = calcFresnelDielectric(wh, wo, mt->ior_in, mt->ior_out);
+    float sqrt_denom = vec3_dot(wo, wh) + eta * vec3_dot(wi, wh);
+    float denom = cos_theta_i * cos_theta_o * sqrt_denom * sqrt_denom;
+    float factor = 1.0f / eta;
+    float numerator = MicrofacetDistribution_D(wh, &mt->distrib) * MicrofacetDistribution_G(wo, wi, &mt->distrib) * eta * eta *
+        fabsf(vec3_dot(wi, wh)) * fabsf(vec3_dot(wo, wh)) * factor * factor;
+    vec3 tmp;
+    vec3_scale(tmp, mt->color, 1.0f - fresnel_reflectance);
+    vec3_scale(f, tmp, fabsf(numerator / denom));
+}
+/* reflection.cpp:447-458 */
+float MicrofacetFresnel_pdf(const vec3 wi, const vec3 wo, const BxDF* mt)
+{
+    if (sameHemisphere(wo, wi)) return 0.0f;
+    float eta = cosTheta(wo) > 0.0f ? (mt->ior_in / mt->ior_out) : (mt->ior_out / mt->ior_in);
+    vec3 wh, scaled_wi;
+    vec3_scale(scaled_wi, wi, eta);
+    vec3_add(wh, wo, scaled_wi);
+    vec3_normalize(wh, wh);
+    float sqrt_denom = vec3_dot(wo, wh) + eta * vec3_dot(wi, wh);
+    float dwh_dwi = fabsf((eta * eta * vec3_dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+    return MicrofacetDistribution_pdf(wo, wh, &mt->distrib) * dwh_dwi;
+}
+/* reflection.cpp:389-445.  The MicrofacetReflection it builds on the stack for the reflected branch leaves is_metal
+ * unset in the reference; it is the dielectric form here (DESIGN.md "N1", deliberate differences). */
+float MicrofacetFresnel_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const BxDF* mt)
+{
+    if (wo[2] == 0.0f) return 0.0f;
+    vec3 wh;
+    MicrofacetDistribution_sample_wh(wh, wo, sample, &mt->distrib);
+    float kr = calcFresnelDielectric(wh, wo, mt->ior_in, mt->ior_out);
+    float rand_float = mt->rand_float;
+    if (rand_float <= kr) {
+        vec3 neg_wo;
+        vec3_negate(neg_wo, wo);
+        calcReflectRayDir(wi, wh, neg_wo);
+        if (!sameHemisphere(wo, wi)) return 0.0f;
+        BxDF mr = *mt;
+        mr.is_metal = false;
+        MicrofacetReflection_f(f, wi, wo, &mr);
+        return MicrofacetDistribution_pdf(wo, wh, &mr.distrib) / (4.0f * vec3_dot(wo, wh));
+    } else {
+        float eta = cosTheta(wo) > 0.0f ? (mt->ior_out / mt->ior_in) : (mt->ior_in / mt->ior_out);
+        if (!refract(wi, wo, wh, eta)) return 0.0f;
+        MicrofacetFresnel_f(f, wi, wo, mt);
+        return MicrofacetFresnel_pdf(wi, wo, mt);
+    }
+}
+
+inline float pow5(float v) { return (v * v) * (v * v) * v; }       /* reflection.cpp:460-463 */
+/* reflection.cpp:465-477 */
+void schlickFresnel(vec3 ret, const float cos_theta, const vec3 Rs)
+{
+    vec3 ones = {1.0f, 1.0f, 1.0f};
+    vec3_sub(ret, ones, Rs);
+    vec3_scale(ret, ret, pow5(1.0f - cos_theta));
+    vec3_add(ret, ret, Rs);
+}
+/* reflection.cpp:479-490 */
+void FresnelBlendDiffuse_f(vec3 f, const vec3 wi, const vec3 wo, const BxDF* fbd)
+{
+    vec3 diffuse;
+    vec3_scale(diffuse, fbd->color, 28.0f / (23.0f * PI));
+    vec3 ones = {1.0f, 1.0f, 1.0f};
+    vec3 one_minus_ks;
+    vec3_sub(one_minus_ks, ones, fbd->ks);
+    vec3_mult(diffuse, diffuse, one_minus_ks);
+    vec3_scale(diffuse, diffuse, 1.0f - pow5(1.0f - 0.5f * absCosTheta(wi)));
+    vec3_scale(diffuse, diffuse, 1.0f - pow5(1.0f - 0.5f * absCosTheta(wo)));
+    vec3_copy(f, diffuse);
+}
+/* reflection.cpp:492-499 */
+float FresnelBlendDiffuse_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const BxDF* fbd)
+{
+    mapSampleToHemisphere(wi, sample);                             /* cosHemisphereSample; its pdf is not used */
+    if (wo[2] < 0.0f) wi[2] = -wi[2];
+    FresnelBlendDiffuse_f(f, wi, wo, fbd);
+    return cosHemispherePdf(wi, wo);
+}
+/* reflection.cpp:507-522 */
+void FresnelBlendSpecular_f(vec3 f, const vec3 wi, const vec3 wo, const BxDF* fbs)
+{
+    vec3 wh;
+    vec3_add(wh, wi, wo);
+    if (vec3_equal(wh, BLACK)) return;
+    vec3_normalize(wh, wh);
+    vec3 specular, fresnel;
+    schlickFresnel(fresnel, vec3_dot(wi, wh), fbs->ks);
+    float cos_theta = vec3_dot(wi, wh);
+    vec3_scale(specular, fresnel, MicrofacetDistribution_D(wh, &fbs->distrib) /
+               (4.0f * fabsf(cos_theta) * maxf(absCosTheta(wi), absCosTheta(wo))));
+    vec3_copy(f, specular);
+}
+/* reflection.cpp:537-547 */
+float FresnelBlendSpecular_pdf(const vec3 wi, const vec3 wo, const BxDF* fbs)
+{
+    if (!sameHemisphere(wo, wi)) return 0.0f;
+    vec3 wh;
+    vec3_add(wh, wo, wi);
+    vec3_normalize(wh, wh);
+    float pdf_wh = MicrofacetDistribution_D(wh, &fbs->distrib);
+    return pdf_wh / (2.0f * vec3_dot(wo, wh));
+}
+/* reflection.cpp:524-535 */
+float FresnelBlendSpecular_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const BxDF* fbs)
+{
+    vec3 wh;
+    MicrofacetDistribution_sample_wh(wh, wo, sample, &fbs->distrib);
+    vec3 neg_wo;
+    vec3_negate(neg_wo, wo);
+    calcReflectRayDir(wi, wh, neg_wo);
+    if (!sameHemisphere(wo, wi)) return 0.0f;
+    FresnelBlendSpecular_f(f, wi, wo, fbs);
+    return FresnelBlendSpecular_pdf(wi, wo, fbs);
+}
+
+/* BxDF_f, reflection.cpp:643-665 */
+void BxDF_f(vec3 f, const vec3 wi, const vec3 wo, const BxDF* bxdf)
+{
+    switch (bxdf->type) {
+    case LAMBERTIAN: vec3_copy(f, bxdf->color); vec3_scale(f, f, INV_PI); return;       /* Lambertian_f, :159-163 */
+    case ORENNAYAR: OrenNayar_f(f, wi, wo, bxdf->color, bxdf->a, bxdf->b); return;
+    case SPECULAR_REFLECTION: case SPECULAR_TRANSMISSION: break;
+    case MICROFACET_REFLECTION: MicrofacetReflection_f(f, wi, wo, bxdf); return;
+    case MICROFACET_FRESNEL: MicrofacetFresnel_f(f, wi, wo, bxdf); return;
+    case FRESNEL_BLEND_DIFFUSE: FresnelBlendDiffuse_f(f, wi, wo, bxdf); return;
+    case FRESNEL_BLEND_SPECULAR: FresnelBlendSpecular_f(f, wi, wo, bxdf); return;
+    }
+}
+/* BxDF_pdf, reflection.cpp:693-717 */
+float BxDF_pdf(const vec3 wi, const vec3 wo, const BxDF* bxdf)
+{
+    switch (bxdf->type) {
+    case LAMBERTIAN: case ORENNAYAR: return cosHemispherePdf(wi, wo);
+    case SPECULAR_REFLECTION: case SPECULAR_TRANSMISSION: return 0.0f;
+    case MICROFACET_REFLECTION: return MicrofacetReflection_pdf(wi, wo, bxdf);
+    case MICROFACET_FRESNEL: return MicrofacetFresnel_pdf(wi, wo, bxdf);
+    case FRESNEL_BLEND_DIFFUSE: return cosHemispherePdf(wi, wo);
+    case FRESNEL_BLEND_SPECULAR: return FresnelBlendSpecular_pdf(wi, wo, bxdf);
+    }
+    return 0.0f;
+}
+/* BxDF_sample_f, reflection.cpp:667-691 */
+float BxDF_sample_f(vec3 f, vec3 wi, const vec3 wo, const vec2 sample, const BxDF* bxdf)
+{
+    switch (bxdf->type) {
+    case LAMBERTIAN: {                                             /* Lambertian_sample_f, :177-189 */
+        vec3 tmp_wo;
+        vec3_copy(tmp_wo, wo);
+        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
+        vec3_copy(f, bxdf->color);
+        vec3_scale(f, f, INV_PI);
+        mapSampleToHemisphere(wi, sample);
+        return cosHemispherePdf(wi, tmp_wo);
+    }
+    case ORENNAYAR: {                                              /* OrenNayar_sample_f, :221-232 */
+        vec3 tmp_wo;
+        vec3_copy(tmp_wo, wo);
+        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
+        mapSampleToHemisphere(wi, sample);
+        float pdf = cosHemispherePdf(wi, tmp_wo);
+        OrenNayar_f(f, wi, wo, bxdf->color, bxdf->a, bxdf->b);
+        return pdf;
+    }
+    case SPECULAR_REFLECTION:                                      /* SpecularReflection_sample_f, :234-241 */
+        vec3_assign(wi, -wo[0], -wo[1], wo[2]);
+        vec3_scale(f, bxdf->color, 1.0f / fabsf(cosTheta(wi)));
+        return 1.0f;
+    case SPECULAR_TRANSMISSION: {                                  /* SpecularTransmission_sample_f, `thin`, :243-270 */
+        const vec3 WHITE = {1.0f, 1.0f, 1.0f};
+        vec3 normal = {0.0f, 0.0f, 1.0f};
+        float cos_theta_o = vec3_dot(normal, wo);
+        if (cos_theta_o < 0.0f) vec3_negate(normal, normal);
+        float kr = calcFresnelDielectric(normal, wo, bxdf->ior_in, bxdf->ior_out);
+        if (bxdf->rand_float <= kr) {
+            vec3_assign(wi, -wo[0], -wo[1], wo[2]);
+            vec3_scale(f, WHITE, kr / fabsf(cosTheta(wi)));
+            return kr;
+        } else {
+            float eta = bxdf->ior_out / bxdf->ior_in;
+            vec3_negate(wi, wo);
+            vec3_scale(f, WHITE, 1.0f - kr);
+            vec3_scale(f, f, (eta * eta) / fabsf(cosTheta(wi)));
+            return 1.0f - kr;
+        }
+    }
+    case MICROFACET_REFLECTION: return MicrofacetReflection_sample_f(f, wi, wo, sample, bxdf);
+    case MICROFACET_FRESNEL: return MicrofacetFresnel_sample_f(f, wi, wo, sample, bxdf);
+    case FRESNEL_BLEND_DIFFUSE: return FresnelBlendDiffuse_sample_f(f, wi, wo, sample, bxdf);
+    case FRESNEL_BLEND_SPECULAR: return FresnelBlendSpecular_sample_f(f, wi, wo, sample, bxdf);
+    }
+    return 0.0f;
+}
+
+/* BSDF_f, reflection.cpp:719-735: the lobes receive the WORLD-space wi, wo (line 731 passes wi, wo, not the
+ * wi_local, wo_local computed above it) */
+void BSDF_f(vec3 f, const vec3 wi, const vec3 wo, const ShadeRec* sr, const int excluded)
+{
+    vec3_copy(f, BLACK);
+    for (int i = 0; i < sr->num_bxdf; i++) {
+        if (!(getBxDFFlagsFromType(sr->bxdfs[i].type) & excluded)) {
+            vec3 cur_f = {0.0f, 0.0f, 0.0f};
+            BxDF_f(cur_f, wi, wo, &sr->bxdfs[i]);
+            vec3_add(f, f, cur_f);
+        }
+    }
+}
+
+/* BSDF_sample_f, reflection.cpp:750-811 */
+float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const vec2 sample, const ShadeRec* sr)
+{
+    if (sr->num_bxdf == 0) { vec3_copy(f, BLACK); *sampled_flags = BSDF_NONE; return 0.0f; }
+    int bxdf_index = (int)(sample[0] * sr->num_bxdf);
+    *sampled_flags = getBxDFFlagsFromType(sr->bxdfs[bxdf_index].type);
+    vec2 remapped_sample = {sample[0] * sr->num_bxdf - bxdf_index, sample[1]};
     vec3 wi_local, wo_local;
     transposeTransform(wo_local, sr->b_tangent, sr->b_binormal, sr->b_normal, wo);
     if (wo_local[2] == 0.0f) { vec3_copy(f, BLACK); return 0.0f; }   /* the reference returns with f unset; the caller only tests pdf */
     vec3_copy(f, BLACK);
-    float pdf;
-    if (mirror) {                                                  /* SpecularReflection_sample_f, reflection.cpp:234-242 */
-        vec3_assign(wi_local, -wo_local[0], -wo_local[1], wo_local[2]);
-        vec3_scale(f, sr->cd, 1.0f / fabsf(wi_local[2]));
-        pdf = 1.0f;
-    } else if (lobe.kind == LOBE_SPECULAR_TRANSMISSION) {          /* SpecularTransmission_sample_f, `thin` (reflection.cpp:243-269) */
-        const vec3 WHITE = {1.0f, 1.0f, 1.0f};
-        vec3 normal = {0.0f, 0.0f, 1.0f};
-        float cos_theta_o = vec3_dot(normal, wo_local);
-        if (cos_theta_o < 0.0f) vec3_negate(normal, normal);
-        float kr = calcFresnelDielectric(normal, wo_local, lobe.ior_in, lobe.ior_out);
-        if (lobe.rand_float <= kr) {
-            vec3_assign(wi_local, -wo_local[0], -wo_local[1], wo_local[2]);
-            vec3_scale(f, WHITE, kr / fabsf(wi_local[2]));
-            pdf = kr;
-        } else {
-            float eta = lobe.ior_out / lobe.ior_in;
-            vec3_negate(wi_local, wo_local);
-            vec3_scale(f, WHITE, 1.0f - kr);
-            vec3_scale(f, f, (eta * eta) / fabsf(wi_local[2]));
-            pdf = 1.0f - kr;
-        }
-    } else if (lobe.kind == LOBE_ORENNAYAR) {                      /* OrenNayar_sample_f, reflection.cpp:221-232 */
-        vec3 tmp_wo;
-        vec3_copy(tmp_wo, wo_local);
-        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
-        mapSampleToHemisphere(wi_local, sample);
-        pdf = cosHemispherePdf(wi_local, tmp_wo);
-        OrenNayar_f(f, wi_local, wo_local, sr->cd, lobe.a, lobe.b);
-    } else {                                                       /* Lambertian_sample_f */
-        vec3 tmp_wo;
-        vec3_copy(tmp_wo, wo_local);
-        if (tmp_wo[2] < 0.0f) tmp_wo[2] *= -1.0f;
-        vec3_copy(f, sr->cd);
-        vec3_scale(f, f, INV_PI);
-        mapSampleToHemisphere(wi_local, sample);
-        pdf = cosHemispherePdf(wi_local, tmp_wo);
-    }
+    vec3_assign(wi_local, 0.0f, 0.0f, 0.0f);
+    float pdf = BxDF_sample_f(f, wi_local, wo_local, remapped_sample, &sr->bxdfs[bxdf_index]);
     if (pdf == 0.0f) { vec3_copy(f, BLACK); return pdf; }
     orthoNormalTransform(wi, sr->b_tangent, sr->b_binormal, sr->b_normal, wi_local);
+    if (!(*sampled_flags & BSDF_SPECULAR)) {
+        for (int i = 0; i < sr->num_bxdf; i++)
+            if (i != bxdf_index) pdf += BxDF_pdf(wi_local, wo_local, &sr->bxdfs[i]);
+    }
+    for (int i = 0; i < sr->num_bxdf; i++) {
+        if (i != bxdf_index) {
+            vec3 cur_f = {0.0f, 0.0f, 0.0f};
+            BxDF_f(cur_f, wi_local, wo_local, &sr->bxdfs[i]);
+            vec3_add(f, f, cur_f);
+        }
+    }
     return pdf;
+}
+
+/* computeScatteringFunc, materials.cpp:111-188, without textures */
+void computeScatteringFunc(ShadeRec* sr, const crt_material* mat, float rand_float)
+{
+    sr->num_bxdf = 0;
+    BxDF b; memset(&b, 0, sizeof b);
+    b.rand_float = rand_float;
+    const vec3 WHITE = {1.0f, 1.0f, 1.0f};
+    switch (mat->type) {
+    case CRT_MAT_MATTE:
+        vec3_copy(b.color, mat->color);
+        if (mat->sigma == 0.0f) b.type = LAMBERTIAN;               /* BSDF_addLambertian */
+        else { b.type = ORENNAYAR; orenNayarAB(mat->sigma, &b.a, &b.b); }
+        sr->bxdfs[sr->num_bxdf++] = b;
+        break;
+    case CRT_MAT_MIRROR:
+        b.type = SPECULAR_REFLECTION; vec3_copy(b.color, mat->color);
+        sr->bxdfs[sr->num_bxdf++] = b;
+        break;
+    case CRT_MAT_TRANSPARENT:
+        b.type = SPECULAR_TRANSMISSION; b.ior_in = mat->ior_in; b.ior_out = mat->ior_out;
+        sr->bxdfs[sr->num_bxdf++] = b;
+        break;
+    case CRT_MAT_PLASTIC: {                                        /* materials.cpp:142-171 */
+        b.type = FRESNEL_BLEND_DIFFUSE; vec3_copy(b.color, mat->color); vec3_copy(b.ks, mat->ks);      /* BSDF_addFresnelBlendDiffuse */
+        sr->bxdfs[sr->num_bxdf++] = b;
+        BxDF s; memset(&s, 0, sizeof s);                           /* BSDF_addFresnelBlendSpecular, reflection.cpp:940-955: alpha = roughness */
+        s.type = FRESNEL_BLEND_SPECULAR; vec3_copy(s.ks, mat->ks);
+        s.distrib.alphax = mat->uroughness; s.distrib.alphay = mat->uroughness;
+        s.ior_in = 1.5f; s.ior_out = 1.0f;
+        sr->bxdfs[sr->num_bxdf++] = s;
+    } break;
+    case CRT_MAT_GLASS:                                            /* materials.cpp:172-178; BSDF_addMicrofacetFresnel, reflection.cpp:899-912 */
+        b.type = MICROFACET_FRESNEL; vec3_copy(b.color, WHITE);
+        b.distrib.alphax = BeckmannRoughnessToAlpha(mat->uroughness);
+        b.distrib.alphay = BeckmannRoughnessToAlpha(mat->vroughness);
+        b.ior_in = mat->ior_in; b.ior_out = mat->ior_out;
+        sr->bxdfs[sr->num_bxdf++] = b;
+        break;
+    case CRT_MAT_METAL:                                            /* materials.cpp:179-186; BSDF_addMicrofacetReflectionMetal, reflection.cpp:879-897 */
+        b.type = MICROFACET_REFLECTION; vec3_copy(b.color, WHITE);
+        b.distrib.alphax = mat->uroughness; b.distrib.alphay = mat->vroughness;
+        vec3_copy(b.etaT, mat->color); vec3_copy(b.etaI, WHITE); vec3_copy(b.k, mat->k);
+        b.is_metal = true;
+        sr->bxdfs[sr->num_bxdf++] = b;
+        break;
+    default: break;
+    }
 }
 
 bool estimateDirect(const Setup& S, vec3 L, const vec2 light_sample, const ShadeRec* sr, const Light& lt)
@@ -406,19 +858,7 @@ bool estimateDirect(const Setup& S, vec3 L, const vec2 light_sample, const Shade
     if (vec3_dot(sample_to_hit_point, sample_normal) > 0.0f || vec3_dot(sample_to_hit_point, sr->normal) < 0.0f) return false;
     vec3 f;
     if (light_pdf > 0.0f && !vec3_equal(Li, BLACK)) {
-        /* BSDF_f: BLACK + Lambertian_f / OrenNayar_f.  BSDF_f hands the lobe the WORLD-space wi, wo
-         * (reflection.cpp:731), which only Oren-Nayar notices */
-        vec3 cur_f = {0.0f, 0.0f, 0.0f};
-        if (sr->mat->type == CRT_MAT_MATTE && sr->mat->sigma != 0.0f) {
-            float a, b;
-            orenNayarAB(sr->mat->sigma, &a, &b);
-            OrenNayar_f(cur_f, wi, sr->wo, sr->cd, a, b);
-        } else {
-            vec3_copy(cur_f, sr->cd);
-            vec3_scale(cur_f, cur_f, INV_PI);
-        }
-        vec3_copy(f, BLACK);
-        vec3_add(f, f, cur_f);
+        BSDF_f(f, wi, sr->wo, sr, BSDF_SPECULAR | BSDF_GLOSSY);    /* excluded_from_direct, trace.h:410 */
         vec3_scale(f, f, fabsf(vec3_dot(sr->normal, wi)));
     } else
         return false;
@@ -495,12 +935,12 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         if (t == TMAX || bounces >= depth || sr.mat->type == CRT_MAT_EMISSIVE) break;
 
         computeLocalBasis(&sr);
-        vec3_copy(sr.cd, sr.mat->color);                           /* computeScatteringFunc: BSDF_addLambertian(color) */
-
         const uint32_t dim0 = 4 + 8 * (uint32_t)bounces;
+        computeScatteringFunc(&sr, sr.mat, rng(dim0 + 2));         /* dim0 + 2 stands in for rand() inside the lobes */
+
         vec2 light_sample = { rng(dim0 + 0), rng(dim0 + 1) };
         /* scatter_sample: dim0 + 2, dim0 + 3, drawn by the reference and unused */
-        if (!(sr.mat->type == CRT_MAT_MIRROR || sr.mat->type == CRT_MAT_TRANSPARENT)) {
+        if (!(sr.mat->type == CRT_MAT_MIRROR || sr.mat->type == CRT_MAT_TRANSPARENT || sr.mat->type == CRT_MAT_GLASS)) {
             vec3 contrib;
             uniformSampleOneLight(S, contrib, light_sample, &sr, rng(dim0 + 6));
             vec3_mult(contrib, contrib, beta);
@@ -510,14 +950,7 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
         vec3 wo, wi, f;
         vec3_negate(wo, ray.d);
         vec2 sample = { rng(dim0 + 4), rng(dim0 + 5) };
-        Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
-        if (sr.mat->type == CRT_MAT_MATTE && sr.mat->sigma != 0.0f) { lobe.kind = LOBE_ORENNAYAR; orenNayarAB(sr.mat->sigma, &lobe.a, &lobe.b); }
-        if (sr.mat->type == CRT_MAT_MIRROR) lobe.kind = LOBE_SPECULAR_REFLECTION;
-        if (sr.mat->type == CRT_MAT_TRANSPARENT) {
-            lobe.kind = LOBE_SPECULAR_TRANSMISSION; lobe.ior_in = sr.mat->ior_in; lobe.ior_out = sr.mat->ior_out;
-            lobe.rand_float = rng(dim0 + 2);                       /* in place of rand() inside the lobe */
-        }
-        float pdf = BSDF_sample_f(f, wi, &sampled_flags, wo, sample, &sr, lobe);
+        float pdf = BSDF_sample_f(f, wi, &sampled_flags, wo, sample, &sr);
         if (vec3_equal(f, BLACK) || pdf == 0.0f) break;
         vec3_scale(f, f, fabsf(vec3_dot(wi, sr.normal)) / pdf);
         vec3_mult(beta, beta, f);
@@ -665,67 +1098,67 @@ void oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* r
 void oracle_trace_disk(const float* in, float* out) { mapSampleToDisk(out, in); }
 void oracle_trace_hemisphere(const float* in, float* out) { mapSampleToHemisphere(out, in); }
 void oracle_trace_local_basis(const float* a, const float* normal, float* out) { getVec3InLocalBasis(out, a, normal); }
+/* One entry for every BSDF piece test: the BSDF computeScatteringFunc builds for `mat`, BSDF_sample_f for (wo, sample)
+ * with rand_float standing in for the lobe's rand(), and BSDF_f for (wi_eval, wo) as estimateDirect calls it (world
+ * vectors, SPECULAR | GLOSSY excluded). */
+float oracle_trace_material_bsdf(const crt_material* mat, float rand_float, const float* basis, const float* wo, const float* sample,
+                                 const float* wi_eval, float* f_out, float* wi_out, int* flags_out, float* f_eval)
+{
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
+    computeScatteringFunc(&sr, mat, rand_float);
+    vec3 wi = {0.0f, 0.0f, 0.0f};
+    int flags = 0;
+    vec3_copy(f_out, BLACK);
+    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr);
+    vec3_copy(wi_out, wi);
+    *flags_out = flags;
+    BSDF_f(f_eval, wi_eval, wo, &sr, BSDF_SPECULAR | BSDF_GLOSSY);
+    return pdf;
+}
 float oracle_trace_lambertian(const float* cd, const float* basis, const float* wo, const float* sample,
                               float* f_out, float* wi_out, float* f_eval)
 {
-    ShadeRec sr; memset(&sr, 0, sizeof sr);
-    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
-    vec3_copy(sr.cd, cd);
-    vec3 wi = {0.0f, 0.0f, 0.0f};
+    crt_material m; memset(&m, 0, sizeof m); m.type = CRT_MAT_MATTE; vec3_copy(m.color, cd);
     int flags = 0;
-    const Lobe lobe = { LOBE_LAMBERTIAN, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
-    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, lobe);
-    vec3_copy(wi_out, wi);
-    vec3 cur_f;                                                    /* BSDF_f as estimateDirect uses it */
-    vec3_copy(cur_f, sr.cd);
-    vec3_scale(cur_f, cur_f, INV_PI);
-    vec3_copy(f_eval, BLACK);
-    vec3_add(f_eval, f_eval, cur_f);
-    return pdf;
+    return oracle_trace_material_bsdf(&m, 0.0f, basis, wo, sample, wo, f_out, wi_out, &flags, f_eval);
 }
-
 float oracle_trace_mirror(const float* cr, const float* basis, const float* wo, float* f_out, float* wi_out, int* flags)
 {
-    ShadeRec sr; memset(&sr, 0, sizeof sr);
-    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
-    vec3_copy(sr.cd, cr);
-    vec3 wi = {0.0f, 0.0f, 0.0f};
+    crt_material m; memset(&m, 0, sizeof m); m.type = CRT_MAT_MIRROR; vec3_copy(m.color, cr);
     const vec2 sample = {0.5f, 0.5f};
-    const Lobe lobe = { LOBE_SPECULAR_REFLECTION, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
-    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
-    vec3_copy(wi_out, wi);
-    return pdf;
+    vec3 fe;
+    return oracle_trace_material_bsdf(&m, 0.0f, basis, wo, sample, wo, f_out, wi_out, flags, fe);
 }
 /* Oren-Nayar: BSDF_sample_f (tangent space) and BSDF_f evaluated for (wi_eval, wo) as given (the reference gives it world vectors) */
 float oracle_trace_orennayar(const float* r, float sigma, const float* basis, const float* wo, const float* sample,
                              const float* wi_eval, float* f_out, float* wi_out, float* f_eval)
 {
-    ShadeRec sr; memset(&sr, 0, sizeof sr);
-    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
-    vec3_copy(sr.cd, r);
-    Lobe lobe = { LOBE_ORENNAYAR, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f };
-    orenNayarAB(sigma, &lobe.a, &lobe.b);
-    vec3 wi = {0.0f, 0.0f, 0.0f};
+    crt_material m; memset(&m, 0, sizeof m); m.type = CRT_MAT_MATTE; vec3_copy(m.color, r); m.sigma = sigma;
     int flags = 0;
-    float pdf = BSDF_sample_f(f_out, wi, &flags, wo, sample, &sr, lobe);
-    vec3_copy(wi_out, wi);
-    vec3 cur_f;
-    OrenNayar_f(cur_f, wi_eval, wo, r, lobe.a, lobe.b);
-    vec3_copy(f_eval, BLACK);
-    vec3_add(f_eval, f_eval, cur_f);
-    return pdf;
+    return oracle_trace_material_bsdf(&m, 0.0f, basis, wo, sample, wi_eval, f_out, wi_out, &flags, f_eval);
 }
 float oracle_trace_transparent(float ior_in, float ior_out, float rand_float, const float* basis, const float* wo,
                                float* f_out, float* wi_out, int* flags)
 {
-    ShadeRec sr; memset(&sr, 0, sizeof sr);
-    vec3_copy(sr.b_tangent, basis); vec3_copy(sr.b_binormal, basis + 3); vec3_copy(sr.b_normal, basis + 6);
-    vec3 wi = {0.0f, 0.0f, 0.0f};
+    crt_material m; memset(&m, 0, sizeof m); m.type = CRT_MAT_TRANSPARENT; m.ior_in = ior_in; m.ior_out = ior_out;
     const vec2 sample = {0.5f, 0.5f};
-    const Lobe lobe = { LOBE_SPECULAR_TRANSMISSION, ior_in, ior_out, rand_float, 0.0f, 0.0f };
-    float pdf = BSDF_sample_f(f_out, wi, flags, wo, sample, &sr, lobe);
-    vec3_copy(wi_out, wi);
-    return pdf;
+    vec3 fe;
+    return oracle_trace_material_bsdf(&m, rand_float, basis, wo, sample, wo, f_out, wi_out, flags, fe);
 }
+/* Beckmann pieces: out = { D(wh), G(wo, wi), Lambda(wo), sample_wh(wo, sample)[3] } */
+void oracle_trace_beckmann(float alphax, float alphay, const float* wo, const float* wi, const float* wh, const float* sample, float* out)
+{
+    MicrofacetDistribution d = { alphax, alphay };
+    out[0] = MicrofacetDistribution_D(wh, &d);
+    out[1] = MicrofacetDistribution_G(wo, wi, &d);
+    out[2] = MicrofacetDistribution_Lambda(wo, &d);
+    MicrofacetDistribution_sample_wh(out + 3, wo, sample, &d);
+}
+void oracle_trace_fresnel_conductor(const float* normal, const float* wo, const float* etaT, const float* etaI, const float* k, float* out)
+{
+    calcFresnelConductor(out, normal, wo, etaT, etaI, k);
+}
+float oracle_trace_roughness_to_alpha(float roughness) { return BeckmannRoughnessToAlpha(roughness); }
 
 } // extern "C"

@@ -595,6 +595,61 @@ REF_API float ref_transparent_bsdf(float ior_in, float ior_out, unsigned seed, c
     return pdf;
 }
 
+/* The BSDF computeScatteringFunc (materials.cpp:142-186) builds for PLASTIC / GLASS / METAL, put together here with the same
+ * BSDF_add* calls (materials.cpp itself needs the texture loader).  BSDF_sample_f after srand(seed) (the glass lobe draws from
+ * rand()), and BSDF_f for (wi_eval, wo) with SPECULAR | GLOSSY excluded, as estimateDirect calls it. */
+REF_API float ref_material_bsdf(const crt_material* m, unsigned seed, const float* basis, const float* wo, const float* sample,
+                                const float* wi_eval, float* f_out, float* wi_out, int* flags_out, float* f_eval)
+{
+    static bool pool = initBSDFMem(1, 4);
+    (void)pool;
+    BSDF bsdf;
+    bsdf.num_bxdf = 0;
+    memcpy(bsdf.tangent, basis, 12); memcpy(bsdf.binormal, basis + 3, 12); memcpy(bsdf.normal, basis + 6, 12);
+    if (m->type == CRT_MAT_PLASTIC) {
+        vec3 kd = { m->color[0], m->color[1], m->color[2] }, ks = { m->ks[0], m->ks[1], m->ks[2] };
+        BSDF_addFresnelBlendDiffuse(&bsdf, kd, ks);
+        BSDF_addFresnelBlendSpecular(&bsdf, ks, 1.5f, 1.0f, m->uroughness, m->uroughness, BECKMANN);
+    } else if (m->type == CRT_MAT_GLASS) {
+        vec3 color = { 1.0f, 1.0f, 1.0f };
+        BSDF_addMicrofacetFresnel(&bsdf, color, m->ior_in, m->ior_out, m->uroughness, m->vroughness, BECKMANN);
+    } else if (m->type == CRT_MAT_METAL) {
+        vec3 color = { 1.0f, 1.0f, 1.0f }, etaI = { 1.0f, 1.0f, 1.0f };
+        vec3 eta = { m->color[0], m->color[1], m->color[2] }, k = { m->k[0], m->k[1], m->k[2] };
+        BSDF_addMicrofacetReflectionMetal(&bsdf, color, eta, etaI, k, m->uroughness, m->vroughness, BECKMANN);
+    } else
+        return -1.0f;
+    vec3 f = { 0, 0, 0 }, wi = { 0, 0, 0 }, w = { wo[0], wo[1], wo[2] }, we = { wi_eval[0], wi_eval[1], wi_eval[2] };
+    vec2 smp = { sample[0], sample[1] };
+    BxDFFlags flags = BSDF_NONE;
+    srand(seed);
+    float pdf = BSDF_sample_f(f, wi, &flags, w, smp, &bsdf);
+    memcpy(f_out, f, 12); memcpy(wi_out, wi, 12);
+    *flags_out = (int)flags;
+    vec3 fe = { 0, 0, 0 };
+    BSDF_f(fe, we, w, &bsdf, (BxDFFlags)(BSDF_SPECULAR | BSDF_GLOSSY));
+    memcpy(f_eval, fe, 12);
+    BSDF_freeBxDFs(&bsdf);
+    return pdf;
+}
+/* the value rand() / RAND_MAX the lobe will see after srand(seed) */
+REF_API float ref_rand_float_after_srand(unsigned seed) { srand(seed); return (float)rand() / (float)RAND_MAX; }
+
+/* Beckmann pieces (microfacet.cpp): out = { D(wh), G(wo, wi), Lambda(wo), sample_wh(wo, sample)[3] } */
+REF_API void ref_beckmann(float alphax, float alphay, const float* wo, const float* wi, const float* wh, const float* sample, float* out)
+{
+    MicrofacetDistribution d; d.alphax = alphax; d.alphay = alphay; d.type = BECKMANN;
+    vec3 o = { wo[0], wo[1], wo[2] }, i = { wi[0], wi[1], wi[2] }, h = { wh[0], wh[1], wh[2] };
+    vec2 smp = { sample[0], sample[1] };
+    out[0] = MicrofacetDistribution_D(h, &d);
+    out[1] = MicrofacetDistribution_G(o, i, &d);
+    out[2] = 1.0f / MicrofacetDistribution_G1(o, &d) - 1.0f;      /* Lambda is not declared in microfacet.h; G1 = 1 / (1 + Lambda) */
+    vec3 r;
+    MicrofacetDistribution_sample_wh(r, o, smp, &d);
+    memcpy(out + 3, r, 12);
+}
+REF_API float ref_roughness_to_alpha(float roughness) { return BeckmannRoughnessToAlpha(roughness); }
+
 /* ---- mesh triangles: the reference's own smooth / flat intersectors and matrix helpers -------- */
 /* rayIntersectSmoothTriangle / rayIntersectFlatTriangle on one triangle of a three-vertex Mesh.  out = hit_point,
  * normal, wo, dpdu; bg = beta, gamma of calcTriangleIntersect (recomputed here with the same function). */

@@ -92,6 +92,12 @@ def _load_oracle(path):
         L.oracle_trace_orennayar.restype = C.c_float
         L.oracle_trace_transparent.argtypes = [C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.oracle_trace_transparent.restype = C.c_float
+        L.oracle_trace_material_bsdf.argtypes = [vp, C.c_float, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]
+        L.oracle_trace_material_bsdf.restype = C.c_float
+        L.oracle_trace_beckmann.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp, vp]
+        L.oracle_trace_beckmann.restype = None
+        L.oracle_trace_roughness_to_alpha.argtypes = [C.c_float]
+        L.oracle_trace_roughness_to_alpha.restype = C.c_float
     return L
 
 
@@ -146,6 +152,14 @@ def ref():
         L.ref_orennayar_bsdf.restype = C.c_float
         L.ref_transparent_bsdf.argtypes = [C.c_float, C.c_float, C.c_uint, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.ref_transparent_bsdf.restype = C.c_float
+        L.ref_material_bsdf.argtypes = [vp, C.c_uint, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]
+        L.ref_material_bsdf.restype = C.c_float
+        L.ref_rand_float_after_srand.argtypes = [C.c_uint]
+        L.ref_rand_float_after_srand.restype = C.c_float
+        L.ref_beckmann.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp, vp]
+        L.ref_beckmann.restype = None
+        L.ref_roughness_to_alpha.argtypes = [C.c_float]
+        L.ref_roughness_to_alpha.restype = C.c_float
         _ref = L
     return _ref
 

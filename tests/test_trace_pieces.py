@@ -222,3 +222,102 @@ def test_shade_rec_of_smooth_and_flat_mesh_triangles():
             else:
                 assert (want[9:] == marker).all()               # rayIntersectFlatTriangle never writes dpdu either
     assert n_hit > 3000
+
+
+def _ulps(a, b):
+    """distance in float32 ulps (same sign assumed where it matters), elementwise"""
+    a = np.asarray(a, np.float32).reshape(-1); b = np.asarray(b, np.float32).reshape(-1)
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def _rand_frame(rng):
+    n = rng.standard_normal(3).astype(np.float32); n /= np.linalg.norm(n)
+    t = np.cross(n, rng.standard_normal(3)).astype(np.float32); t /= np.linalg.norm(t)
+    b = np.cross(n, t).astype(np.float32)
+    return np.concatenate([t, b, n]).astype(np.float32)
+
+
+def _unit(rng):
+    v = rng.standard_normal(3).astype(np.float32)
+    return (v / np.linalg.norm(v)).astype(np.float32)
+
+
+def test_beckmann_pieces():
+    """MicrofacetDistribution_D / _G / Lambda / _sample_wh (microfacet.cpp, BECKMANN), isotropic and anisotropic.  The
+    restatement rounds exp / log / tan / atan once from double where the reference calls glibc's float routines, so a
+    last-ulp difference is allowed where those enter (D, sample_wh); G and Lambda use none of them and must be identical."""
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(21)
+    worst, differing, n = 0, 0, 6000
+    for k in range(n):
+        ax = np.float32(0.02 + rng.random() * 0.8)
+        ay = ax if k % 2 == 0 else np.float32(0.02 + rng.random() * 0.8)
+        wo, wi, wh = _unit(rng), _unit(rng), _unit(rng)
+        if k % 50 == 0:
+            wh = np.array([1.0, 0.0, 0.0], np.float32)           # tan^2 theta infinite -> D = 0
+        smp = rng.random(2, dtype=np.float32)
+        a, b = np.zeros(6, np.float32), np.zeros(6, np.float32)
+        L.oracle_trace_beckmann(ax, ay, _p(wo), _p(wi), _p(wh), _p(smp), _p(a))
+        R.ref_beckmann(ax, ay, _p(wo), _p(wi), _p(wh), _p(smp), _p(b))
+        assert ol.same_bits(a[1:2], b[1:2])                      # G
+        assert abs(float(a[2]) - float(b[2])) <= 3e-7 * max(1.0, abs(float(b[2])))   # Lambda, recovered from the reference's G1 as 1/G1 - 1
+        # D, and the direction: a 1-ulp change of log / tan moves a component of wh by a few ulps of the largest one
+        assert _ulps(a[0], b[0]).max() <= 2, (a[0], b[0])
+        assert np.abs(a[3:] - b[3:]).max() <= 4e-6, (a, b)    # sin_theta = sqrt(1 - cos^2) amplifies the ulp when cos_theta is near 1
+        u = int(max(_ulps(a[0], b[0]).max(), (a[3:] != b[3:]).any()))
+        differing += u > 0
+    assert differing < 0.02 * n, differing
+
+
+@pytest.mark.parametrize("kind", ["PLASTIC", "METAL", "GLASS"])
+def test_glossy_material_bsdfs(kind):
+    """The BSDFs of PLASTIC (FresnelBlendDiffuse + FresnelBlendSpecular: two lobes, so the lobe pick, the remapped sample
+    and the added pdf / f of the other lobe are exercised), METAL (MicrofacetReflection, conductor Fresnel) and GLASS
+    (MicrofacetFresnel: reflection or refraction picked by rand(), replayed through srand) against the reference's
+    reflection.cpp / microfacet.cpp: flags identical, pdf / f / wi within the last-ulp allowance of the transcendental
+    functions (see test_beckmann_pieces), the fraction of results that are not bit-identical reported and bounded;
+    BSDF_f as estimateDirect calls it (world vectors, glossy lobes excluded) identical."""
+    L, R = ol.oracle(), ol.ref()
+    rng = np.random.default_rng({"PLASTIC": 31, "METAL": 32, "GLASS": 33}[kind])
+    n, inexact, zero_pdf, refl, refr = 4000, 0, 0, 0, 0
+    for k in range(n):
+        basis = _rand_frame(rng)
+        wo, we = _unit(rng), _unit(rng)
+        smp = rng.random(2, dtype=np.float32)
+        ur = float(np.float32(0.05 + rng.random() * 0.6))
+        vr = ur if k % 3 else float(np.float32(0.05 + rng.random() * 0.6))
+        if kind == "PLASTIC":
+            m = api.material(api.MAT_PLASTIC, rng.random(3), ks=rng.random(3) * 0.6, uroughness=ur)
+        elif kind == "METAL":
+            eta, kk = list(api.METALS.values())[k % len(api.METALS)]
+            m = api.material(api.MAT_METAL, eta, k=kk, uroughness=ur, vroughness=vr)
+        else:
+            m = api.material(api.MAT_GLASS, (1, 1, 1), ior_in=1.5 if k % 4 else 1.33, ior_out=1.0, uroughness=ur, vroughness=vr)
+        marr = np.array([m], api.MATERIAL_DTYPE)
+        seed = 1000 + k
+        u = R.ref_rand_float_after_srand(seed)
+        fa, wa, ea, fb, wb, eb = (np.zeros(3, np.float32) for _ in range(6))
+        ga, gb = C.c_int(0), C.c_int(0)
+        pa = L.oracle_trace_material_bsdf(_p(marr), u, _p(basis), _p(wo), _p(smp), _p(we), _p(fa), _p(wa), C.byref(ga), _p(ea))
+        pb = R.ref_material_bsdf(_p(marr), seed, _p(basis), _p(wo), _p(smp), _p(we), _p(fb), _p(wb), C.byref(gb), _p(eb))
+        assert ga.value == gb.value
+        assert ol.same_bits(ea, eb)                                # BSDF_f for the direct-light estimate
+        assert (pa == 0.0) == (pb == 0.0), (pa, pb, wo, smp)
+        if pb == 0.0:
+            zero_pdf += 1
+            continue
+        tol = 2e-5                                                # a last-ulp change of exp's argument path, amplified by 1 / alpha^2
+        assert abs(pa - pb) <= tol * abs(pb), (pa, pb)
+        assert np.abs(fa - fb).max() <= tol * max(np.abs(fb).max(), 1e-30), (fa, fb)
+        assert np.abs(wa - wb).max() <= 2e-6, (wa, wb)
+        inexact += not (np.float32(pa) == np.float32(pb) and ol.same_bits(fa, fb) and ol.same_bits(wa, wb))
+        if kind == "GLASS":
+            wl = basis.reshape(3, 3) @ wa
+            ol_ = basis.reshape(3, 3) @ wo
+            refl += (wl[2] * ol_[2]) > 0
+            refr += (wl[2] * ol_[2]) < 0
+    print(kind, "results not bit-identical to the reference: %d of %d (zero pdf: %d)" % (inexact, n - zero_pdf, zero_pdf))
+    assert inexact < 0.05 * n
+    assert zero_pdf < 0.6 * n
+    if kind == "GLASS":
+        assert refl > 50 and refr > 500
