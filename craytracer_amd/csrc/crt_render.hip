@@ -113,6 +113,250 @@ __device__ __forceinline__ float fresnel_dielectric(float nz, float woz, float e
     return (r_parl * r_parl + r_perp * r_perp) / 2;
 }
 
+/* calcFresnelDielectric for any normal: only vec3_dot(n, wo) enters the result */
+__device__ __forceinline__ float fresnel_dielectric_cos(float cos_theta_i, float etaT, float etaI)
+{
+    return fresnel_dielectric(1.0f, cos_theta_i, etaT, etaI);     /* 1 * c is c */
+}
+
+/* ---- PLASTIC / GLASS / METAL: microfacet.cpp and the glossy lobes of reflection.cpp -------------------------------------
+ * exp / log / tan / atan: the double-precision function rounded once, as in the oracle (glibc's float routines are not
+ * correctly rounded and no device libm returns their bits; against the reference that is a last-ulp difference in about
+ * 1 % of the lobe evaluations, tests/test_trace_pieces.py).  cosf / sinf are glibc's (crt_libm.h). */
+__device__ __forceinline__ float r_expf(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float r_logf(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float r_tanf(float x) { return (float)tan((double)x); }
+__device__ __forceinline__ float r_atanf(float x) { return (float)atan((double)x); }
+__device__ __forceinline__ float maxr(float a, float b) { return (a > b) ? a : b; }                  /* util/util.h:14 */
+__device__ __forceinline__ float mf_cos_phi(V3 w) { const float st = on_sin_theta(w); return (st == 0) ? 1.0f : on_clamp(w.x / st); }
+__device__ __forceinline__ float mf_sin_phi(V3 w) { const float st = on_sin_theta(w); return (st == 0) ? 0.0f : on_clamp(w.y / st); }
+__device__ __forceinline__ bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }              /* util/math.h:49-52 */
+__device__ __forceinline__ float pow5(float v) { return (v * v) * (v * v) * v; }                      /* reflection.cpp:460-463 */
+
+/* MicrofacetDistribution_D, BECKMANN, microfacet.cpp:4-21 */
+__device__ float beckmann_D(V3 wh, float ax, float ay)
+{
+    const float c2 = wh.z * wh.z;
+    const float tan2 = maxr(0.0f, 1.0f - c2) / c2;
+    if (isinf(tan2)) return 0.0f;
+    const float cos4 = c2 * c2;
+    const float cp = mf_cos_phi(wh), sp = mf_sin_phi(wh);
+    const float e = r_expf(-tan2 * (cp * cp / (ax * ax) + sp * sp / (ay * ay)));
+    return (float)((double)e / (RD_PI * (double)ax * (double)ay * (double)cos4));
+}
+/* MicrofacetDistribution_Lambda / _G, microfacet.cpp:33-55,:72-75 */
+__device__ float beckmann_lambda(V3 w, float ax, float ay)
+{
+    const float abs_tan = fabsf(on_sin_theta(w) / w.z);
+    if (isinf(abs_tan)) return 0.0f;
+    const float cp = mf_cos_phi(w), sp = mf_sin_phi(w);
+    const float alpha = sqrtf(cp * cp * ax * ax + sp * sp * ay * ay);
+    const float a = 1.0f / (alpha * abs_tan);
+    if (a >= 1.6f) return 0.0f;
+    return (1.0f - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+}
+__device__ __forceinline__ float beckmann_G(V3 wo, V3 wi, float ax, float ay)
+{
+    return 1.0f / (1.0f + beckmann_lambda(wo, ax, ay) + beckmann_lambda(wi, ax, ay));
+}
+/* MicrofacetDistribution_sample_wh, microfacet.cpp:77-135 */
+__device__ V3 beckmann_sample_wh(V3 wo, float s0, float s1, float ax, float ay)
+{
+    float tan2, phi;
+    float log_sample = r_logf(s0);
+    if (isinf(log_sample)) log_sample = 0.0f;
+    if (ax == ay) {
+        tan2 = -ax * ax * log_sample;
+        phi = (float)((double)(s1 * 2.0f) * RD_PI);
+    } else {
+        phi = r_atanf(ay / ax * r_tanf((float)(2.0f * RD_PI * (double)s1 + 0.5f * RD_PI)));
+        if (s1 > 0.5f) phi = (float)((double)phi + RD_PI);
+        const float sin_phi = crt_libm_sinf(phi), cos_phi = crt_libm_cosf(phi);
+        const float ax2 = ax * ax, ay2 = ay * ay;
+        tan2 = -log_sample / (cos_phi * cos_phi / ax2 + sin_phi * sin_phi / ay2);
+    }
+    const float cos_theta = 1.0f / sqrtf(1.0f + tan2);
+    const float sin_theta = sqrtf(maxr(0.0f, 1.0f - cos_theta * cos_theta));
+    V3 wh = v3(sin_theta * crt_libm_cosf(phi), sin_theta * crt_libm_sinf(phi), cos_theta);            /* sphericalDirection, util/math.h:91-93 */
+    if (!same_hemisphere(wo, wh)) wh = neg(wh);
+    return wh;
+}
+/* calcFresnelConductor, reflection.cpp:78-157, one colour channel */
+__device__ float fresnel_conductor(float cos_theta_i, float etaT, float etaI, float k)
+{
+    const float c2 = cos_theta_i * cos_theta_i, s2 = 1.0f - c2;
+    const float eta = etaT / etaI, etaK = k / etaI;
+    const float eta2 = eta * eta, etaK2 = etaK * etaK;
+    float t0 = eta2 - etaK2;
+    t0 = t0 - s2;
+    float e22 = eta2 * etaK2;
+    e22 = e22 * 4.0f;
+    const float a2plusb2 = sqrtf(t0 * t0 + e22);
+    const float t1 = a2plusb2 + c2;
+    float a = a2plusb2 + t0;
+    a = a * 0.5f;
+    a = sqrtf(a);
+    const float t2 = a * (2.0f * cos_theta_i);
+    const float rs = (t1 - t2) / (t1 + t2);
+    float t3 = a2plusb2 * c2;
+    t3 = t3 + s2 * s2;
+    const float t4 = t2 * s2;
+    float rp = (t3 - t4) / (t3 + t4);
+    rp = rp * rs;
+    return (rp + rs) * 0.5f;
+}
+/* calcReflectRayDir(wi, wh, -wo), util/ray.cpp:11-17 */
+__device__ __forceinline__ V3 reflect_about(V3 wo, V3 wh)
+{
+    const V3 inc = neg(wo);
+    const float magnitude = -2.0f * dot(inc, wh);
+    return add(inc, scale(wh, magnitude));
+}
+/* MicrofacetReflection_f, reflection.cpp:297-327: *f is written only when the lobe has a value (the callers start from black).
+ * m: the device copy of the material (alpha in uroughness / vroughness).  metal: conductor Fresnel with etaT = color, etaI = 1. */
+__device__ void mf_reflection_f(V3* f, V3 wi, V3 wo, const crt_material& m, bool metal)
+{
+    const float cos_o = fabsf(wo.z), cos_i = fabsf(wi.z);
+    V3 wh = add(wi, wo);
+    if (cos_i == 0.0f || cos_o == 0.0f) return;
+    if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return;
+    wh = normalize(wh);
+    V3 fr;
+    if (!metal) {
+        const float kr = 1.0f - fresnel_dielectric_cos(dot(wh, wi), m.ior_in, m.ior_out);
+        fr = v3(kr, kr, kr);
+    } else {
+        const float c = dot(wi, wh);
+        fr = v3(fresnel_conductor(c, m.color[0], 1.0f, m.k[0]), fresnel_conductor(c, m.color[1], 1.0f, m.k[1]),
+                fresnel_conductor(c, m.color[2], 1.0f, m.k[2]));
+    }
+    const float sf = beckmann_D(wh, m.uroughness, m.vroughness) * beckmann_G(wo, wi, m.uroughness, m.vroughness) / (4.0f * cos_i * cos_o);
+    *f = mul(scale(v3(1.0f, 1.0f, 1.0f), sf), fr);                 /* color = white for METAL and GLASS, materials.cpp:175,:182 */
+}
+/* MicrofacetFresnel_f / _pdf, reflection.cpp:356-387,:447-458 */
+__device__ void mf_fresnel_f(V3* f, V3 wi, V3 wo, const crt_material& m)
+{
+    if (same_hemisphere(wo, wi)) return;
+    const float cos_o = wo.z, cos_i = wi.z;
+    if (cos_i == 0.0f || cos_o == 0.0f) { *f = v3(0.f, 0.f, 0.f); return; }
+    const float eta = cos_o > 0.0f ? (m.ior_in / m.ior_out) : (m.ior_out / m.ior_in);
+    V3 wh = normalize(add(wo, scale(wi, eta)));
+    if (wh.z < 0.0f) wh = neg(wh);
+    const float F = fresnel_dielectric_cos(dot(wh, wo), m.ior_in, m.ior_out);
+    const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+    const float denom = cos_i * cos_o * sqrt_denom * sqrt_denom;
+    const float factor = 1.0f / eta;
+    const float numerator = beckmann_D(wh, m.uroughness, m.vroughness) * beckmann_G(wo, wi, m.uroughness, m.vroughness) * eta * eta *
+        fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor;
+    *f = scale(scale(v3(1.0f, 1.0f, 1.0f), 1.0f - F), fabsf(numerator / denom));
+}
+__device__ float mf_fresnel_pdf(V3 wi, V3 wo, const crt_material& m)
+{
+    if (same_hemisphere(wo, wi)) return 0.0f;
+    const float eta = wo.z > 0.0f ? (m.ior_in / m.ior_out) : (m.ior_out / m.ior_in);
+    const V3 wh = normalize(add(wo, scale(wi, eta)));
+    const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+    const float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+    return beckmann_D(wh, m.uroughness, m.vroughness) * fabsf(wh.z) * dwh_dwi;
+}
+/* FresnelBlendDiffuse_f, reflection.cpp:479-490 (kd = color) */
+__device__ V3 fb_diffuse_f(V3 wi, V3 wo, const crt_material& m)
+{
+    V3 d = scale(v3p(m.color), (float)(28.0f / (23.0f * RD_PI)));
+    d = mul(d, sub(v3(1.0f, 1.0f, 1.0f), v3p(m.ks)));
+    d = scale(d, 1.0f - pow5(1.0f - 0.5f * fabsf(wi.z)));
+    d = scale(d, 1.0f - pow5(1.0f - 0.5f * fabsf(wo.z)));
+    return d;
+}
+/* FresnelBlendSpecular_f / _pdf, reflection.cpp:507-522,:537-547 */
+__device__ void fb_specular_f(V3* f, V3 wi, V3 wo, const crt_material& m)
+{
+    V3 wh = add(wi, wo);
+    if (is_black(wh)) return;
+    wh = normalize(wh);
+    const float c = dot(wi, wh);
+    const V3 ks = v3p(m.ks);
+    const V3 fresnel = add(scale(sub(v3(1.0f, 1.0f, 1.0f), ks), pow5(1.0f - c)), ks);                 /* schlickFresnel, :465-477 */
+    *f = scale(fresnel, beckmann_D(wh, m.uroughness, m.vroughness) / (4.0f * fabsf(c) * maxr(fabsf(wi.z), fabsf(wo.z))));
+}
+__device__ float fb_specular_pdf(V3 wi, V3 wo, const crt_material& m)
+{
+    if (!same_hemisphere(wo, wi)) return 0.0f;
+    const V3 wh = normalize(add(wo, wi));
+    return beckmann_D(wh, m.uroughness, m.vroughness) / (2.0f * dot(wo, wh));
+}
+__device__ __forceinline__ float cos_hemisphere_pdf(V3 wi, V3 wo)                                     /* reflection.cpp:6-15 */
+{
+    return same_hemisphere(wi, wo) ? (float)((double)fabsf(wi.z) * RD_INV_PI) : 0.0f;
+}
+/* BSDF_sample_f (reflection.cpp:750-811) for the BSDFs of PLASTIC (two lobes), GLASS and METAL (materials.cpp:142-186), in
+ * tangent space.  Returns the pdf (0: the path ends); *glossy = the sampled lobe's flags hold GLOSSY.
+ * u_rand stands in for rand() in MicrofacetFresnel_sample_f (reflection.cpp:419). */
+__device__ __noinline__ float glossy_sample_f(const crt_material& m, V3 wo, float s0, float s1, float u_rand, V3* f_out, V3* wi_out, bool* glossy)
+{
+    V3 f = v3(0.f, 0.f, 0.f), wi = v3(0.f, 0.f, 0.f);
+    float pdf = 0.0f;
+    const float ax = m.uroughness, ay = m.vroughness;
+    if (m.type == CRT_MAT_METAL) {                                /* MicrofacetReflection_sample_f, :329-344 */
+        *glossy = true;
+        if (wo.z == 0.0f) return 0.0f;
+        const V3 wh = beckmann_sample_wh(wo, s0, s1, ax, ay);
+        wi = reflect_about(wo, wh);
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        mf_reflection_f(&f, wi, wo, m, true);
+        pdf = beckmann_D(wh, ax, ay) * fabsf(wh.z) / (4.0f * dot(wo, wh));
+    } else if (m.type == CRT_MAT_GLASS) {                         /* MicrofacetFresnel_sample_f, :389-445 */
+        *glossy = true;
+        if (wo.z == 0.0f) return 0.0f;
+        const V3 wh = beckmann_sample_wh(wo, s0, s1, ax, ay);
+        const float kr = fresnel_dielectric_cos(dot(wh, wo), m.ior_in, m.ior_out);
+        if (u_rand <= kr) {
+            wi = reflect_about(wo, wh);
+            if (!same_hemisphere(wo, wi)) return 0.0f;
+            mf_reflection_f(&f, wi, wo, m, false);                /* the stack MicrofacetReflection's is_metal, unset there, is false here */
+            pdf = beckmann_D(wh, ax, ay) * fabsf(wh.z) / (4.0f * dot(wo, wh));
+        } else {
+            const float eta = wo.z > 0.0f ? (m.ior_out / m.ior_in) : (m.ior_in / m.ior_out);
+            /* refract, util/ray.cpp:42-59 */
+            const float cos_i = dot(wh, wo);
+            const float sin2_i = maxr(0.0f, 1.0f - cos_i * cos_i);
+            const float sin2_t = eta * eta * sin2_i;
+            if (sin2_t >= 1.0f) return 0.0f;
+            const float cos_t = sqrtf(1.0f - sin2_t);
+            wi = add(scale(neg(wo), eta), scale(wh, eta * cos_i - cos_t));
+            mf_fresnel_f(&f, wi, wo, m);
+            pdf = mf_fresnel_pdf(wi, wo, m);
+        }
+    } else {                                                      /* PLASTIC: [0] FresnelBlendDiffuse, [1] FresnelBlendSpecular */
+        const int idx = (int)(s0 * 2);
+        const float r0 = s0 * 2 - idx;
+        if (idx == 0) {                                           /* FresnelBlendDiffuse_sample_f, :492-499 */
+            *glossy = false;
+            wi = sample_hemisphere(r0, s1);
+            if (wo.z < 0.0f) wi.z = -wi.z;
+            f = fb_diffuse_f(wi, wo, m);
+            pdf = cos_hemisphere_pdf(wi, wo);
+            if (pdf == 0.0f) return 0.0f;
+            pdf += fb_specular_pdf(wi, wo, m);
+            V3 g = v3(0.f, 0.f, 0.f);
+            fb_specular_f(&g, wi, wo, m);
+            f = add(f, g);
+        } else {                                                  /* FresnelBlendSpecular_sample_f, :524-535 */
+            *glossy = true;
+            const V3 wh = beckmann_sample_wh(wo, r0, s1, ax, ay);
+            wi = reflect_about(wo, wh);
+            if (!same_hemisphere(wo, wi)) return 0.0f;
+            fb_specular_f(&f, wi, wo, m);
+            pdf = fb_specular_pdf(wi, wo, m);
+            if (pdf == 0.0f) return 0.0f;
+            pdf += cos_hemisphere_pdf(wi, wo);
+            f = add(f, fb_diffuse_f(wi, wo, m));
+        }
+    }
+    *f_out = f; *wi_out = wi;
+    return pdf;
+}
+
 /* crt_rng: DESIGN.md "N1".  Three rounds of the murmur3 finaliser over (seed, pixel, sample, dim). */
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -288,7 +532,8 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             const float ls0 = RNG(DIM_LIGHT), ls1 = RNG(DIM_LIGHT + 1);
             /* scatter_sample (trace.h:469) is drawn and never used: dimensions DIM_SCATTER, +1 stay reserved */
             /* ---- uniformSampleOneLight, trace.h:359-397 ---- */
-            if (rd.num_lights > 0 && mat.type != CRT_MAT_MIRROR && mat.type != CRT_MAT_TRANSPARENT) {   /* trace.h:470 */
+            if (rd.num_lights > 0 && mat.type != CRT_MAT_MIRROR && mat.type != CRT_MAT_TRANSPARENT && mat.type != CRT_MAT_GLASS &&
+                mat.type != CRT_MAT_METAL) {                      /* trace.h:470; METAL's one lobe is GLOSSY, which BSDF_f excludes (trace.h:410): its estimate is black */
                 const float u = RNG(DIM_PICK);
                 int li = rd.num_lights - 1;                       /* the reference leaves light_index unset when no interval matches */
                 float sel_pdf = rd.lights[li].power;
@@ -339,7 +584,8 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 const V3 Li = scale(v3p(lt.color), lt.intensity);
                 const V3 s2h = sub(sp, hp);
                 if (!(dot(s2h, sn) > 0.0f || dot(s2h, normal) < 0.0f) && lpdf > 0.0f && !is_black(Li)) {
-                    V3 f = oren ? scale(cd, oren_nayar_scale(wi, wo, mat.ior_in, mat.ior_out))    /* OrenNayar_f on the WORLD vectors */
+                    V3 f = mat.type == CRT_MAT_PLASTIC ? fb_diffuse_f(wi, wo, mat)                /* the DIFFUSE lobe of the two, on the WORLD vectors too */
+                         : oren ? scale(cd, oren_nayar_scale(wi, wo, mat.ior_in, mat.ior_out))    /* OrenNayar_f on the WORLD vectors */
                                 : scale(cd, (float)RD_INV_PI);    /* Lambertian_f, reflection.cpp:159-163 */
                     f = scale(f, fabsf(dot(normal, wi)));
                     if (!is_black(f)) {
@@ -383,6 +629,9 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                         f = scale(f, (eta * eta) / fabsf(wi_l.z));
                         pdf = 1.0f - kr;
                     }
+                } else if (mat.type == CRT_MAT_PLASTIC || mat.type == CRT_MAT_GLASS || mat.type == CRT_MAT_METAL) {
+                    pdf = glossy_sample_f(mat, wo_l, bs0, bs1, RNG(DIM_SCATTER), &f, &wi_l, &spec);
+                    if (pdf == 0.0f) { f = v3(0.f, 0.f, 0.f); wi_l = v3(0.f, 0.f, 1.0f); }
                 } else {                                          /* Lambertian_sample_f, reflection.cpp:177-189 */
                     spec = false;
                     const float two_z = fabsf(wo_l.z);            /* tmp_wo flipped into the upper hemisphere */
@@ -528,7 +777,8 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (4 + 8ull * ((unsigned long long)d->max_depth + 1) > 0xFFFFFFFFull) return CRT_E_TOOBIG;
     for (int m = 0; m < d->num_materials; m++) {
         const crt_material& mt = d->materials[m];
-        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT) return CRT_E_UNSUPPORTED;
+        if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT &&
+            mt.type != CRT_MAT_PLASTIC && mt.type != CRT_MAT_GLASS && mt.type != CRT_MAT_METAL) return CRT_E_UNSUPPORTED;
     }
     std::vector<ShadeObj> objs((size_t)in->num_obj);
     std::vector<LightRec> lights;
@@ -647,6 +897,18 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     ok = ok && hipMemcpy(d_objs, objs.data(), objs.size() * sizeof(ShadeObj), hipMemcpyHostToDevice) == hipSuccess;
     std::vector<crt_material> dev_mats(d->materials, d->materials + d->num_materials);
     for (crt_material& m : dev_mats) {
+        /* the device copy carries the Beckmann alphas in uroughness / vroughness: BSDF_addFresnelBlendSpecular and
+         * BSDF_addMicrofacetReflectionMetal take the roughness as alpha, BSDF_addMicrofacetFresnel maps it through
+         * BeckmannRoughnessToAlpha (reflection.cpp:879-955; microfacet.h:25-31 -- host code, glibc's logf as there) */
+        if (m.type == CRT_MAT_PLASTIC) m.vroughness = m.uroughness;                   /* materials.cpp:168-169 passes roughness twice */
+        if (m.type == CRT_MAT_GLASS) {
+            float* rough[2] = { &m.uroughness, &m.vroughness };
+            for (float* pr : rough) {
+                const float rr = (*pr > (float)1e-3) ? *pr : (float)1e-3;
+                const float x = logf(rr);
+                *pr = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+            }
+        }
         if (m.type != CRT_MAT_MATTE || m.sigma == 0.0f) continue;
         const float sigma_rad = m.sigma / 180.0f * (float)RD_PI;  /* BSDF_addOrenNayar, reflection.cpp:823-830; degToRad, util/math.h:65 */
         const float sigma2 = sigma_rad * sigma_rad;

@@ -208,7 +208,7 @@ def cornell_camera(width, height, fov=0.6911, L=None):
 
 
 def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intensity=0.25, samples_in_flight=0,
-                tri_type=None, mirrors=False, glass=False, rough=False):
+                tri_type=None, mirrors=False, glass=False, rough=False, glossy=False):
     """A displaced blob (TRIANGLE objects) in a unit room of 12 triangles, two matte spheres, a sphere
     light, a disk light, a rectangle light under the ceiling (slightly tilted, so its box is not flat)
     and a constant environment light seen through nothing (the room is closed) but sampled:
@@ -231,7 +231,7 @@ def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intens
     sl.sphere((0.18, 0.12, 0.75), 0.12); mat_of.append(9 if glass else 5)
     if glass:                                             # a thin pane across the room in front of the camera
         sl.rectangle((0.1, 0.1, 0.8), (0.8, 0.0, 0.02), (0.0, 0.7, 0.0)); mat_of.append(9)
-    sl.sphere((0.82, 0.10, 0.70), 0.10); mat_of.append(8 if mirrors else 0)
+    sl.sphere((0.82, 0.10, 0.70), 0.10); mat_of.append(8 if (mirrors or glossy) else 0)
     sl.sphere((0.85, 0.80, 0.20), 0.05); mat_of.append(6)                                   # sphere light
     sl.disk((0.02, 0.5, 0.5), _normalize32((1.0, 0.1, 0.0)), 0.15); mat_of.append(7)            # disk light on the left wall
     mats = np.array([
@@ -244,6 +244,13 @@ def render_room(n_lat=64, n_lon=128, seed=3, max_depth=5, rng_seed=7, env_intens
     ], api.MATERIAL_DTYPE)
     if rough:                                             # Oren-Nayar walls and blob (sigma in degrees)
         mats[0]["sigma"], mats[1]["sigma"], mats[3]["sigma"] = 20.0, 35.0, 60.0
+    if glossy:                                            # PLASTIC walls and blob, a gold and a rough-glass sphere, a brushed-copper wall
+        mats[0] = api.material(api.MAT_PLASTIC, (0.6, 0.6, 0.58), ks=(0.25, 0.25, 0.25), uroughness=0.12)
+        mats[3] = api.material(api.MAT_PLASTIC, (0.5, 0.35, 0.1), ks=(0.4, 0.4, 0.3), uroughness=0.3)
+        gold, copper = api.METALS["GOLD"], api.METALS["COPPER"]
+        mats[5] = api.material(api.MAT_METAL, gold[0], k=gold[1], uroughness=0.08)
+        mats[2] = api.material(api.MAT_METAL, copper[0], k=copper[1], uroughness=0.05, vroughness=0.35)     # anisotropic
+        mats[8] = api.material(api.MAT_GLASS, (1, 1, 1), ior_in=1.5, ior_out=1.0, uroughness=0.1, vroughness=0.1)
     si = sl.to_input()
     env = ((1.0, 1.0, 1.0), env_intensity, 3.5) if env_intensity is not None else None
     desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=env, samples_in_flight=samples_in_flight)

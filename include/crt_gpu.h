@@ -263,8 +263,9 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
  *   geometry  TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE (interpolated normals; needs crt_mesh_shading), RECTANGLE,
  *             SPHERE; DISK only with an EMISSIVE material;
- *   materials MATTE without texture (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR (specular
- *             reflection, materials.cpp:129-136), TRANSPARENT (thin specular transmission, :137-141), EMISSIVE;
+ *   materials every MatType, without textures: MATTE (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR
+ *             (specular reflection, :129-136), TRANSPARENT (thin specular transmission, :137-141), PLASTIC (Fresnel-blend
+ *             diffuse + specular lobes, :142-171), GLASS (rough dielectric, :172-178), METAL (:179-186), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
  *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform); no MeshLights
  *             (EMISSIVE on FLAT / SMOOTH triangles is refused; on plain TRIANGLE objects it only emits).

@@ -1,5 +1,6 @@
-/* Compares craytracer_amd/csrc/crt_libm.h with the platform libm on every float in [0, 2*pi]
- * (and a band beyond); prints the number of differing results.  Built and run by tests/test_libm.py. */
+/* Compares craytracer_amd/csrc/crt_libm.h with the platform libm on every float in [-6.5, 6.5]
+ * ([0, 2*pi] and a band beyond for the sampling maps; the negative half for the anisotropic Beckmann
+ * azimuth, microfacet.cpp:121-124); prints the number of differing results.  Built and run by tests/test_libm.py. */
 #include <math.h>
 #include <stdio.h>
 #include <stdbool.h>
@@ -10,9 +11,12 @@ int main(void)
     unsigned long long bad = 0, n = 0;
     for (uint32_t u = 0; u <= uh; u++) {
         float f; memcpy(&f, &u, 4);
-        const float a = sinf(f), b = crt_libm_sinf(f), c = cosf(f), d = crt_libm_cosf(f);
-        bad += (memcmp(&a, &b, 4) != 0) + (memcmp(&c, &d, 4) != 0);
-        n++;
+        for (int neg = 0; neg < 2; neg++) {
+            const float g = neg ? -f : f;
+            const float a = sinf(g), b = crt_libm_sinf(g), c = cosf(g), d = crt_libm_cosf(g);
+            bad += (memcmp(&a, &b, 4) != 0) + (memcmp(&c, &d, 4) != 0);
+            n++;
+        }
     }
     printf("%llu %llu\n", n, bad);
     return bad != 0;

@@ -103,6 +103,26 @@ def test_oren_nayar_matte():
     assert not ol.same_bits(want, osc.render(smooth, cam, flm, 0, 4))
 
 
+def test_plastic_glass_and_metal():
+    """PLASTIC (two lobes: FresnelBlendDiffuse + FresnelBlendSpecular), GLASS (MicrofacetFresnel, rough, reflecting or
+    refracting by one random number) and METAL (MicrofacetReflection with the conductor Fresnel term, one of them
+    anisotropic), all Beckmann.  exp / log / tan / atan are double-precision results rounded once on both sides, so the
+    images are expected to agree bit for bit here too; the bar written down is the weaker one the float functions
+    justify: at most 1 pixel in 1 000 may differ."""
+    si, desc, pos, look = scenes.render_room(24, 48, max_depth=6, rng_seed=41, glossy=True)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 96, 96)
+    got, _, _ = gpu_render(si, desc, cam, flm, api.ACCEL_BVH4, [4])
+    osc = ol.OracleScene(si, api.ACCEL_BVH4)
+    want = osc.render(desc, cam, flm, 0, 4)
+    assert np.isfinite(got).all() and got.max() > 0
+    same = (got == want).all(axis=2).mean()
+    print("glossy room: %.5f of the pixels bit-identical" % same)
+    assert same >= 0.999
+    _, matte, _, _ = scenes.render_room(24, 48, max_depth=6, rng_seed=41)
+    assert not ol.same_bits(want, osc.render(matte, cam, flm, 0, 4))
+
+
 @pytest.mark.parametrize("smooth", [True, False])
 def test_baked_mesh_with_interpolated_or_face_normals(smooth):
     """A mesh baked by crt_bake_mesh into SMOOTH_TRIANGLE objects (normals and tangents interpolated with the hit's
@@ -187,7 +207,7 @@ def test_unsupported_scenes_are_refused():
     built = api.BuiltScene(si, api.ACCEL_NONE)
     scene = api.Scene(built)
     mats = desc.materials.copy()
-    mats[1]["type"] = 16                                             # PLASTIC
+    mats[1]["type"] = 128                                            # not a MatType
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
     assert e.value.code == -4

@@ -1,5 +1,5 @@
 """craytracer_amd/csrc/crt_libm.h (the device's cosf / sinf for the sampling maps) against the platform
-libm -- the one the reference links -- on every float in [0, 6.5]: all 2 x 1.09e9 results identical."""
+libm -- the one the reference links -- on every float in [-6.5, 6.5]: all 4 x 1.09e9 results identical."""
 import os
 import subprocess
 
@@ -11,4 +11,4 @@ def test_every_float_up_to_two_pi(tmp_path):
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-x", "c++", "-o", exe, os.path.join(HERE, "libm_check.c"), "-lm"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     n, bad = (int(x) for x in out.stdout.split())
-    assert out.returncode == 0 and bad == 0 and n > 1_000_000_000
+    assert out.returncode == 0 and bad == 0 and n > 2_000_000_000
