@@ -801,9 +801,10 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         const crt_material& mt = d->materials[mi];
         ShadeObj so; memset(&so, 0, sizeof so);
         so.type = type; so.mat = mi;
-        /* emissive mesh triangles become MeshLights (initMeshLights, buildscene.h:749-) that enter the power CDF but that
-         * estimateDirect cannot sample ("Invalid light type", trace.h:311-313): not part of this form */
-        if (mt.type == CRT_MAT_EMISSIVE && (type == CRT_FLAT_TRIANGLE || type == CRT_SMOOTH_TRIANGLE)) return CRT_E_UNSUPPORTED;
+        /* EMISSIVE mesh triangles: initMeshLights (buildscene.h:749-833) registers them as MeshLights, which preprocessLights
+         * gives no power (no MESHLIGHT case, buildscene.h:879-917) and estimateDirect cannot sample ("Invalid light type",
+         * trace.h:311-313).  For pathTrace they are surfaces that emit when a camera ray or a specular / glossy bounce finds them;
+         * no light record is made. */
         if (type == CRT_SMOOTH_TRIANGLE) {
             if (ref < 0 || ref >= in->num_tris || !in->tri_verts) return CRT_E_INVALID;
             if (!ms || !ms->vertex_normals || !ms->vertex_tangents || !ms->normal_mat_index || !ms->normal_mats) return CRT_E_UNSUPPORTED;

@@ -267,8 +267,9 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  *             (specular reflection, :129-136), TRANSPARENT (thin specular transmission, :137-141), PLASTIC (Fresnel-blend
  *             diffuse + specular lobes, :142-171), GLASS (rough dielectric, :172-178), METAL (:179-186), EMISSIVE;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
- *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform); no MeshLights
- *             (EMISSIVE on FLAT / SMOOTH triangles is refused; on plain TRIANGLE objects it only emits).
+ *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform); EMISSIVE
+ *             triangles of any kind emit when a path finds them and are never sampled (the reference's MeshLights
+ *             carry no power, buildscene.h:879-917, and estimateDirect has no case for them, trace.h:311-313).
  * Random numbers: the reference draws from per-thread sample tables (Sampler_getSample) and from libc
  * rand() (trace.h:371,:516), both dependent on thread scheduling.  Here every number is
  * crt_rng(seed, pixel, sample, dimension) (definition in DESIGN.md "N1"), so an image is a pure

@@ -1024,7 +1024,8 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
         if (type != CRT_TRIANGLE && type != CRT_FLAT_TRIANGLE && type != CRT_SMOOTH_TRIANGLE && type != CRT_RECTANGLE && type != CRT_SPHERE &&
             type != CRT_DISK) return -1;
         if (type == CRT_DISK && mat.type != CRT_MAT_EMISSIVE) return -1;
-        if (mat.type == CRT_MAT_EMISSIVE && (type == CRT_FLAT_TRIANGLE || type == CRT_SMOOTH_TRIANGLE)) return -1;   /* MeshLight */
+        /* EMISSIVE on FLAT / SMOOTH triangles: a MeshLight in the reference, with zero power (preprocessLights has no MESHLIGHT case)
+         * and not sampleable by estimateDirect (trace.h:311-313): emits when found, never chosen */
         if ((type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) && mat.type == CRT_MAT_EMISSIVE) {
             Light l; l.kind = 1; l.obj_type = type; l.shape = in->shapes[in->obj_ref[i]].p;
             vec3_copy(l.color, mat.color); l.intensity = mat.intensity;

@@ -135,6 +135,23 @@ def test_baked_mesh_with_interpolated_or_face_normals(smooth):
     compare(got, want)
 
 
+def test_emissive_mesh_triangles_emit_but_are_not_sampled():
+    """EMISSIVE on SMOOTH / FLAT triangles (the reference's MeshLights: no power, no case in estimateDirect): seen by camera
+    rays, never chosen as a light."""
+    for smooth in (True, False):
+        si, desc, pos, look = scenes.smooth_blob_room(12, 24, smooth=smooth, max_depth=4)
+        om = desc.obj_material.copy()
+        first_blob = int(np.nonzero(si.obj_type != api.TRIANGLE)[0][0]) if (si.obj_type != api.TRIANGLE).any() else 12
+        emissive = int(np.nonzero(desc.materials["type"] == api.MAT_EMISSIVE)[0][0])
+        om[first_blob:first_blob + 200:3] = emissive             # every third triangle of the first 200 glows
+        d2 = api.RenderDesc(si, om, desc.materials, 4, seed=9, env=None, mesh_shading=desc.mesh_shading)
+        cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+        flm = api.make_film(cam, 1.2, 80, 64)
+        got, _, _ = gpu_render(si, d2, cam, flm, api.ACCEL_BVH4, [3])
+        want = ol.OracleScene(si, api.ACCEL_BVH4).render(d2, cam, flm, 0, 3)
+        compare(got, want)
+
+
 def test_flat_triangles_keep_their_winding_normal():
     si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
@@ -221,13 +238,8 @@ def test_unsupported_scenes_are_refused():
         api.Renderer(api.Scene(api.BuiltScene(other, api.ACCEL_BVH4)), desc, cam, flm)
     assert e.value.code == -1
     s3, d3, _, _ = scenes.smooth_blob_room(8, 16)
-    om3 = d3.obj_material.copy()
-    om3[20] = 2                                                      # an EMISSIVE mesh triangle would be a MeshLight
     b3 = api.BuiltScene(s3, api.ACCEL_BVH4)
     sc3 = api.Scene(b3)
-    with pytest.raises(api.CrtError) as e:
-        api.Renderer(sc3, api.RenderDesc(s3, om3, d3.materials, 3, mesh_shading=d3.mesh_shading), cam, flm)
-    assert e.value.code == -4
     with pytest.raises(api.CrtError) as e:                           # SMOOTH_TRIANGLE objects without their shading arrays
         api.Renderer(sc3, api.RenderDesc(s3, d3.obj_material, d3.materials, 3), cam, flm)
     assert e.value.code == -4
