@@ -141,6 +141,7 @@ class CrtRenderStats(C.Structure):
 
 # every symbol include/crt_gpu.h declares
 EXPORTS = [
+    "crt_scene_file_load", "crt_scene_file_get", "crt_scene_file_free", "crt_env_world_radius",
     "crt_build_scene", "crt_build_scene_ex", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
@@ -383,6 +384,77 @@ class MeshShading:
         c.normal_mat_index, c.normal_mats = _ptr(self.normal_mat_index), _ptr(self.normal_mats)
         c.num_normal_mats = 0 if self.normal_mats is None else len(self.normal_mats.reshape(-1, 9))
         self.c = c
+
+
+class CrtSceneFileView(C.Structure):
+    _fields_ = [("input", CrtSceneInput), ("obj_material", C.POINTER(C.c_int32)), ("materials", C.c_void_p),
+                ("material_names", C.POINTER(C.c_char_p)), ("num_materials", C.c_int32), ("has_mesh_shading", C.c_int32),
+                ("mesh_shading", CrtMeshShading), ("has_film", C.c_int32), ("window_width", C.c_int32), ("window_height", C.c_int32),
+                ("image_width", C.c_int32), ("image_height", C.c_int32), ("fov", C.c_float), ("has_camera", C.c_int32),
+                ("camera_pos", C.c_float * 3), ("look_point", C.c_float * 3), ("has_env_light", C.c_int32),
+                ("env_color", C.c_float * 3), ("env_intensity", C.c_float), ("num_skipped", C.c_int32), ("num_unsupported", C.c_int32)]
+
+
+class SceneFile:
+    """crt_scene_file_load: a scene description file (scene/scenefile.h grammar, and the older one of the files the
+    reference ships) as SceneInput + materials + camera / film / env light.  Arrays are copied out of the C object."""
+
+    def __init__(self, path, L=None):
+        L = L or lib()
+        L.crt_scene_file_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.crt_scene_file_get.argtypes = [C.c_void_p]
+        L.crt_scene_file_get.restype = C.POINTER(CrtSceneFileView)
+        L.crt_scene_file_free.argtypes = [C.c_void_p]
+        L.crt_scene_file_free.restype = None
+        h = C.c_void_p()
+        _check(L.crt_scene_file_load(os.fsencode(path), C.byref(h)), "crt_scene_file_load")
+        try:
+            v = L.crt_scene_file_get(h).contents
+            n, nt, ns, nm = v.input.num_obj, v.input.num_tris, v.input.num_shapes, v.num_materials
+
+            def arr(ptr, count, dtype):
+                if not ptr or count == 0:
+                    return np.zeros(count, dtype)
+                return np.frombuffer(C.string_at(ptr, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
+            self.scene_input = SceneInput(arr(v.input.tri_verts, nt * 9, np.float32).reshape(-1, 9), arr(v.input.shapes, ns, SHAPE_DTYPE),
+                                          arr(v.input.obj_type, n, np.int32), arr(v.input.obj_ref, n, np.int32))
+            self.obj_material = arr(C.cast(v.obj_material, C.c_void_p).value, n, np.int32)
+            self.materials = arr(v.materials, nm, MATERIAL_DTYPE)
+            self.material_names = [v.material_names[i].decode() for i in range(nm)]
+            self.mesh_shading = None
+            if v.has_mesh_shading:
+                ms = v.mesh_shading
+                self.mesh_shading = MeshShading(arr(ms.flat_normal, nt * 3, np.float32).reshape(-1, 3),
+                                                arr(ms.vertex_normals, nt * 9, np.float32).reshape(-1, 9),
+                                                arr(ms.vertex_tangents, nt * 9, np.float32).reshape(-1, 9),
+                                                arr(ms.normal_mat_index, nt, np.int32),
+                                                arr(ms.normal_mats, ms.num_normal_mats * 9, np.float32).reshape(-1, 9))
+            self.film = (v.window_width, v.window_height, v.image_width, v.image_height, float(v.fov)) if v.has_film else None
+            self.camera = (tuple(v.camera_pos), tuple(v.look_point)) if v.has_camera else None
+            self.env_light = (tuple(v.env_color), float(v.env_intensity)) if v.has_env_light else None
+            self.num_skipped, self.num_unsupported = v.num_skipped, v.num_unsupported
+        finally:
+            L.crt_scene_file_free(h)
+
+    def render_desc(self, max_depth, built=None, seed=0, samples_in_flight=0, world_radius=None):
+        """RenderDesc for this scene.  The env light's world radius comes from the built accelerator as in
+        preprocessLights (crt_env_world_radius) unless given."""
+        env = None
+        if self.env_light is not None:
+            if world_radius is None:
+                world_radius = env_world_radius(built)
+            env = (self.env_light[0], self.env_light[1], world_radius)
+        return RenderDesc(self.scene_input, self.obj_material, self.materials, max_depth, seed=seed, env=env,
+                          samples_in_flight=samples_in_flight, mesh_shading=self.mesh_shading)
+
+
+def env_world_radius(built, L=None):
+    """crt_env_world_radius (preprocessLights, buildscene.h:839-873) of a BuiltScene."""
+    L = L or lib()
+    L.crt_env_world_radius.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    r = C.c_float()
+    _check(L.crt_env_world_radius(C.addressof(built.desc), C.byref(r)), "crt_env_world_radius")
+    return float(r.value)
 
 
 def bake_mesh(positions, indices, scaling, orientation, location, normals=None, tangents=None, L=None):

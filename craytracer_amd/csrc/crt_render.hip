@@ -784,7 +784,8 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     std::vector<LightRec> lights;
     const crt_mesh_shading* ms = d->mesh_shading;
     bool any_smooth = false;
-    if (d->has_env_light) {                                       /* the scene file's ENV_LIGHT precedes the objects: light 0 */
+    if (d->has_env_light && d->env_intensity > 0.0f) {            /* the scene file's ENV_LIGHT precedes the objects: light 0; with intensity <= 0 it
+                                                                     is seen (black) but is no light, buildscene.h:525-533 */
         LightRec l; memset(&l, 0, sizeof l);
         l.kind = LIGHT_ENV; l.obj_type = -1;
         memcpy(l.color, d->env_color, sizeof l.color);

@@ -387,6 +387,41 @@ void crt_obj_free(crt_obj_shape* shapes, int32_t num_shapes);
 int  crt_mesh_normals_tangents(const float* positions, int32_t num_vertices, const int32_t* indices, int32_t num_indices,
                                const float* normals_in, float* normals_out, float* tangents_out);
 
+/* ---- scene description files, host side ------------------------------ */
+/* loadSceneFile + setupFilmAndCamera (buildscene.h:344-539) with the parse* functions of scene/scenefile.h:18-791:
+ * film and camera header, MATERIAL entries of all seven types, OBJECT entries (SPHERE PLANE RECTANGLE TRIANGLE BOX
+ * OPENCYLINDER DISK TORUS SOLIDCYLINDER MESH), ENV_LIGHT.  Objects come out in file order as a crt_scene_input (meshes
+ * loaded by crt_obj_load and flattened by crt_bake_mesh), materials as crt_material records, obj_material[i] = index
+ * of object i's material (-1: the name is not defined, the reference's NULL).  The older grammar of the scene files
+ * the reference ships (DIFF_COLOR / AMB_COLOR materials, no film header) is read too; textures are not loaded.
+ * Everything the view points to lives until crt_scene_file_free. */
+typedef struct crt_scene_file crt_scene_file;
+typedef struct crt_scene_file_view {
+    crt_scene_input     input;
+    const int32_t*      obj_material;        /* [input.num_obj] */
+    const crt_material* materials;
+    const char* const*  material_names;      /* [num_materials] */
+    int32_t             num_materials;
+    int32_t             has_mesh_shading;    /* any OBJECT MESH entry: mesh_shading is indexed like input.tri_verts */
+    crt_mesh_shading    mesh_shading;
+    int32_t             has_film;            /* WINDOW_WIDTH .. FOV present */
+    int32_t             window_width, window_height, image_width, image_height;
+    float               fov;                 /* radians (degToRad of the file's value, buildscene.h:365) */
+    int32_t             has_camera;
+    float               camera_pos[3], look_point[3];
+    int32_t             has_env_light;       /* an ENV_LIGHT entry; with intensity <= 0 it is no light and black (buildscene.h:525-533) */
+    float               env_color[3], env_intensity;
+    int32_t             num_skipped;         /* object entries dropped: unknown kind, no MATERIAL field, unreadable mesh file */
+    int32_t             num_unsupported;     /* textures, unknown material / metal types: kept as placeholders */
+} crt_scene_file_view;
+int  crt_scene_file_load(const char* path, crt_scene_file** out);
+const crt_scene_file_view* crt_scene_file_get(const crt_scene_file* sf);
+void crt_scene_file_free(crt_scene_file* sf);
+/* EnvLight.world_radius as preprocessLights derives it from the built accelerator (buildscene.h:839-873): twice the
+ * diagonal of the BVH root / grid box, and for the QBVH the expression written there.  NONE: CRT_E_UNSUPPORTED (the
+ * reference leaves the field unset). */
+int  crt_env_world_radius(const crt_scene_desc* desc, float* radius);
+
 /* ---- image state and 8-bit output, host side ---------------------- */
 /* saveImageState / readImageState (imagestate.h:5-43): "<num_samples>\n<width> <height>\n" followed by
  * width*height*3 raw float32 sums -- the file the reference resumes from (main.cpp:238-253) and the

@@ -1008,7 +1008,7 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
     S.scene = scene; S.d = d; S.seed = d->seed;
     const crt_scene_input* in = d->objects;
     triangleSetup(&S, in);
-    if (d->has_env_light) {
+    if (d->has_env_light && d->env_intensity > 0.0f) {             /* buildscene.h:525-533 */
         Light l; l.kind = 0; l.obj_type = -1; l.shape = 0;
         vec3_copy(l.color, d->env_color); l.intensity = d->env_intensity;
         float power = (l.color[0] + l.color[1] + l.color[2]) / 3.0f;

@@ -108,6 +108,43 @@ static int obj_and_mesh_checks()
     return 0;
 }
 
+/* crt_scenefile.cpp on hostile text: truncated entries, keywords without values, numbers that are not numbers, very long
+ * tokens, entries nested in each other, and random token soup; then the view of a good file built into every accelerator */
+static int scene_file_checks()
+{
+    const char* path = "/tmp/crt_sanitize_scene.txt";
+    const char* words[] = { "MATERIAL", "MATTE", "MIRROR", "TRANSPARENT", "EMISSIVE", "PLASTIC", "GLASS", "METAL", "NAME", "a", "COLOR", "RED", "0.5", "SIGMA", "END",
+        "END_MATERIALS", "OBJECT", "SPHERE", "PLANE", "RECTANGLE", "TRIANGLE", "BOX", "TORUS", "OPENCYLINDER", "SOLIDCYLINDER", "DISK", "MESH", "RADIUS", "CENTER",
+        "POINT", "NORMAL", "WIDTH", "HEIGHT", "LENGTH", "V0", "V1", "V2", "LOCATION", "SCALE", "ORIENTATION", "NORMAL_TYPE", "OPEN", "bogus", "FILE_NAME", "/nonexistent.obj",
+        "SMOOTH", "yes", "ENV_LIGHT", "TYPE", "CONSTANT", "TEXTURE", "x.exr", "INTENSITY", "-1", "1e39", "nan", "#", "#x", "\n", "\t", "\r\n", "KD", "KS", "ROUGHNESS", "GOLD",
+        "WINDOW_WIDTH", "FOV", "CAMERA_POS", "LOOK_POINT", "0", "0 0 0", "1 2", "" };
+    const int nw = (int)(sizeof words / sizeof words[0]);
+    for (int round = 0; round < 400; round++) {
+        std::string text;
+        const int len = 1 + rand() % 120;
+        for (int i = 0; i < len; i++) { text += words[rand() % nw]; text += (rand() % 5 == 0) ? "\n" : " "; }
+        if (round % 50 == 0) text += std::string(5000, 'Z');       // one very long token
+        if (write_file(path, text)) return 1;
+        crt_scene_file* sf = 0;
+        if (crt_scene_file_load(path, &sf) != CRT_OK || !sf) { printf("scene file round %d refused\n", round); return 1; }
+        const crt_scene_file_view* v = crt_scene_file_get(sf);
+        if (v->input.num_obj < 0 || v->num_materials < 0) { printf("scene file counts\n"); return 1; }
+        for (int i = 0; i < v->input.num_obj; i++)
+            if (v->obj_material[i] < -1 || v->obj_material[i] >= v->num_materials) { printf("scene file material index\n"); return 1; }
+        char what[64]; snprintf(what, sizeof what, "scene file round %d", round);
+        if (v->input.num_obj > 0 && build_all(v->input, what, true)) return 1;     // NaN / zero-extent geometry: the grid may refuse
+        crt_scene_file_free(sf);
+    }
+    crt_scene_file* sf = 0;
+    if (crt_scene_file_load(0, &sf) != CRT_E_INVALID || crt_scene_file_load("/nonexistent/scene.txt", &sf) != CRT_E_INVALID ||
+        crt_scene_file_load(path, 0) != CRT_E_INVALID || crt_scene_file_get(0) != 0) { printf("scene file argument checks\n"); return 1; }
+    crt_scene_file_free(0);
+    float r = 0;
+    if (crt_env_world_radius(0, &r) != CRT_E_INVALID) { printf("world radius null check\n"); return 1; }
+    remove(path);
+    return 0;
+}
+
 int main()
 {
     const int sizes[] = { 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 29, 30, 31, 32, 33, 63, 64, 65, 127, 1000, 4099 };
@@ -155,6 +192,7 @@ int main()
         crt_built_scene_destroy(0);
     }
     if (obj_and_mesh_checks()) return 1;
+    if (scene_file_checks()) return 1;
     printf("host_sanitize ok\n");
     return 0;
 }

@@ -152,6 +152,28 @@ def test_emissive_mesh_triangles_emit_but_are_not_sampled():
         compare(got, want)
 
 
+def test_scene_file_end_to_end():
+    """tests/golden/scene_all.txt (this repository's own file in the reference's grammar: all seven material types, rectangle /
+    sphere / triangle / disk objects, a smooth and a flat OBJ mesh, film, camera, env light) -> crt_scene_file_load -> builder
+    -> preprocessLights' world radius -> renderer, against the oracle on the same description."""
+    import os
+    sf = api.SceneFile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_all.txt"))
+    built = api.BuiltScene(sf.scene_input, api.ACCEL_BVH4)
+    desc = sf.render_desc(5, built=built, seed=3)
+    (pos, look), (_, _, w, h, fov) = sf.camera, sf.film
+    cam = api.make_camera(pos, look)
+    flm = api.make_film(cam, fov, w, h)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, desc, cam, flm)
+    r.render(4)
+    got, _ = r.read()
+    r.close(); scene.close()
+    want = ol.OracleScene(sf.scene_input, built=built).render(desc, cam, flm, 0, 4)
+    assert np.isfinite(got).all() and got.max() > 0
+    same = (got == want).all(axis=2).mean()
+    assert same >= 0.999, same
+
+
 def test_flat_triangles_keep_their_winding_normal():
     si, desc, pos, look = scenes.render_room(16, 32, max_depth=3, rng_seed=9, tri_type=api.FLAT_TRIANGLE)
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
