@@ -418,7 +418,7 @@ def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, s
 
 
 def courtyard_render(n_copies, n_lat, n_lon, seed=5, room=10.0, max_depth=5, rng_seed=1, env_intensity=1.0,
-                     samples_in_flight=0):
+                     samples_in_flight=0, glossy=False):
     """The courtyard() stand-in as a render scene: TRIANGLE objects, open to the sky (the two ceiling
     triangles removed), lit by a constant environment light -- "incoherent diffuse bounces" of
     BASELINE.json's last config.  White walls, four blob colours.  Returns (SceneInput, RenderDesc,
@@ -433,6 +433,12 @@ def courtyard_render(n_copies, n_lat, n_lon, seed=5, room=10.0, max_depth=5, rng
     mats = np.array([api.material(api.MAT_MATTE, (0.74, 0.74, 0.73)), api.material(api.MAT_MATTE, (0.6, 0.3, 0.2)),
                      api.material(api.MAT_MATTE, (0.3, 0.55, 0.25)), api.material(api.MAT_MATTE, (0.25, 0.35, 0.6)),
                      api.material(api.MAT_MATTE, (0.7, 0.65, 0.4))], api.MATERIAL_DTYPE)
+    if glossy:                                                      # the blobs in plastic, gold, rough glass and brushed copper
+        gold, copper = api.METALS["GOLD"], api.METALS["COPPER"]
+        mats[1] = api.material(api.MAT_PLASTIC, (0.6, 0.3, 0.2), ks=(0.3, 0.3, 0.3), uroughness=0.2)
+        mats[2] = api.material(api.MAT_METAL, gold[0], k=gold[1], uroughness=0.1)
+        mats[3] = api.material(api.MAT_GLASS, (1, 1, 1), ior_in=1.5, ior_out=1.0, uroughness=0.15, vroughness=0.15)
+        mats[4] = api.material(api.MAT_METAL, copper[0], k=copper[1], uroughness=0.05, vroughness=0.3)
     desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=((1.0, 1.0, 1.0), env_intensity, 4.0 * room),
                           samples_in_flight=samples_in_flight)
     return si, desc, (room * 0.5, room * 0.3, room * 0.97), (room * 0.5, room * 0.2, 0.0)

@@ -24,10 +24,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--in-flight", type=int, default=0)
+    ap.add_argument("--glossy", action="store_true", help="blobs in PLASTIC / METAL / GLASS instead of MATTE")
+    ap.add_argument("--builder", default="sah", choices=["sah", "reference"])
     a = ap.parse_args()
     t0 = time.time()
-    si, desc, pos, look = scenes.courtyard_render(a.copies, a.lat, a.lon, max_depth=a.depth, samples_in_flight=a.in_flight)
-    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    si, desc, pos, look = scenes.courtyard_render(a.copies, a.lat, a.lon, max_depth=a.depth, samples_in_flight=a.in_flight, glossy=a.glossy)
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=a.builder == "sah")
     scene = api.Scene(built)
     t_build = time.time() - t0
     cam = api.make_camera(pos, look, focal_pt_dist=0.05)
@@ -43,8 +45,8 @@ def main():
     img, ns = r.read()
     rays = (s1["rays_closest"] - s0["rays_closest"]) + (s1["rays_shadow"] - s0["rays_shadow"])
     out = {
-        "metric": "samples/sec/pixel", "value": a.spp / dt, "workload": "courtyard-%dk-open, QBVH, %dx%d, depth %d" % (
-            si.num_obj // 1000, a.width, a.height, a.depth),
+        "metric": "samples/sec/pixel", "value": a.spp / dt, "workload": "courtyard-%dk-open, %s, QBVH (%s split), %dx%d, depth %d" % (
+            si.num_obj // 1000, "plastic / metal / glass blobs" if a.glossy else "matte", a.builder, a.width, a.height, a.depth),
         "spp_timed": a.spp, "seconds": dt, "mrays_per_s_all_queries": rays / dt / 1e6,
         "rays_closest": s1["rays_closest"] - s0["rays_closest"], "rays_shadow": s1["rays_shadow"] - s0["rays_shadow"],
         "ms_extend_kernels": s1["ms_extend"] - s0["ms_extend"], "ms_shadow_kernels": s1["ms_shadow"] - s0["ms_shadow"],
