@@ -271,13 +271,18 @@ void build4(Builder& B, NodeCountCache& ncc, int first, int count, int self, int
 /* ---- SAH QBVH (CRT_BUILD_SAH) ------------------------------------------------------------------
  * Same node format, same leaf rule (a child with <= 4 objects is a leaf) and the same traversal as the
  * reference's tree; only the choice of the three split planes of a node differs: binned surface-area
- * heuristic over object centroids (32 bins per axis, all three axes) instead of the object median on
+ * heuristic over object centroids (16 bins per axis, all three axes) instead of the object median on
  * the longest axis (bvh4.h:143-195).  Hits do not depend on the tree for objects that lie inside their
  * boxes, so results are those of the reference's tree except for which of two exactly equal-t hits is
  * found first.  The reference's builder balances by count, so a few scene-sized triangles (walls, a
  * ground quad) bloat the boxes of every level they pass through; SAH puts them in their own subtrees.
  * Depth is bounded for the traversal stack: near the limit the builder falls back to median splits. */
-const int SAH_BINS = 32;
+/* 16 bins: measured against 4 / 8 / 12 / 20 / 24 / 32 / 64 / 128 on the 10.5 M-triangle courtyard; more planes lower the
+ * greedy cost of each split without making the tree better */
+#ifndef CRT_SAH_BINS
+#define CRT_SAH_BINS 16
+#endif
+const int SAH_BINS = CRT_SAH_BINS;
 const int SAH_MAX_DEPTH = 20;                       /* levels; the pruned walk allows 21 (3 * depth + 1 <= 64) */
 
 inline float box_area(const Box& b)
