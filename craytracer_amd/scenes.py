@@ -376,7 +376,40 @@ def courtyard(n_copies, n_lat, n_lon, seed=5, room=10.0):
     return api.SceneInput(np.concatenate(parts, 0))
 
 
-def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, seed=11):
+def icosphere(level, seed=3, displace=0.12):
+    """Indexed icosphere subdivided `level` times (20 * 4^level well-shaped triangles, shared vertices), radius displaced
+    by a few low-frequency sine lobes: the S3 "Buddha ~1M triangles" stand-in (level 8: 1 310 720 triangles).
+    Returns (positions [V, 3], normals [V, 3], tangents [V, 3], indices [T, 3])."""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(level):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+        e.sort(axis=1)
+        uniq, inv = np.unique(e[:, 0] * (len(v) + 1) + e[:, 1], return_inverse=True)
+        a, b = uniq // (len(v) + 1), uniq % (len(v) + 1)
+        mid = v[a] + v[b]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        m = len(v) + inv.reshape(3, -1)                            # midpoint index of edge k of every face
+        v = np.concatenate([v, mid], 0)
+        f = np.concatenate([np.stack([f[:, 0], m[0], m[2]], 1), np.stack([f[:, 1], m[1], m[0]], 1),
+                            np.stack([f[:, 2], m[2], m[1]], 1), np.stack([m[0], m[1], m[2]], 1)], 0)
+    rng = np.random.default_rng(seed)
+    rad = np.ones(len(v))
+    for k in range(6):
+        d = rng.standard_normal(3); d /= np.linalg.norm(d)
+        rad += displace / (k + 1) * np.sin((2 + k) * (v @ d) * math.pi + rng.random() * 6.28)
+    pos = v * rad[:, None]
+    nrm = v.copy()                                                 # the sphere's normals: smooth, close enough for a displaced blob
+    tan = np.cross(np.array([0.0072, 1.0, 0.0034]), nrm)
+    tan /= np.linalg.norm(tan, axis=1, keepdims=True)
+    return pos.astype(F32), nrm.astype(F32), tan.astype(F32), f.astype(np.int32)
+
+
+def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, seed=11, blob_material=None, mesh=None):
     """A unit room of TRIANGLE walls with a sphere light and, baked through crt_bake_mesh (generateMeshTriangles) with a
     non-uniform scale and a rotation, one indexed lat-long blob with per-vertex normals and tangents: SMOOTH_TRIANGLE
     objects (smooth=True) or FLAT_TRIANGLE objects carrying FlatTriangle.normal.  Returns (SceneInput, RenderDesc, pos, look)."""
@@ -394,8 +427,10 @@ def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, s
             a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
             c, d = a + n_lon, b + n_lon
             idx += [a, c, b, b, c, d]
+    if mesh is not None:                                           # (positions, normals, tangents, indices) instead of the lat-long blob
+        pos, nrm, tan, idx = mesh
     baked = api.bake_mesh(pos, idx, scaling=(0.22, 0.3, 0.2), orientation=(25.0, -15.0, 40.0), location=(0.5, 0.4, 0.45),
-                          normals=nrm.astype(F32), tangents=tan)
+                          normals=np.asarray(nrm, F32), tangents=tan)
     walls = room_tris((0, 0, 0), (1, 1, 1))
     nw, nb = len(walls), len(baked["tri_verts"])
     tris = np.concatenate([walls, baked["tri_verts"]], 0)
@@ -412,6 +447,8 @@ def smooth_blob_room(n_lat=24, n_lon=48, smooth=True, max_depth=5, rng_seed=3, s
                          normal_mat_index=np.zeros(nw + nb, np.int32), normal_mats=baked["normal_mat"].reshape(1, 9))
     mats = np.array([api.material(api.MAT_MATTE, (0.7, 0.7, 0.68)), api.material(api.MAT_MATTE, (0.6, 0.45, 0.25), sigma=25.0),
                      api.material(api.MAT_EMISSIVE, (1.0, 0.9, 0.8), 60.0)], api.MATERIAL_DTYPE)
+    if blob_material is not None:
+        mats[1] = blob_material
     mat_of = [0] * nw + [1] * nb + [2]
     desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=((0.6, 0.7, 1.0), 0.2, 3.5), mesh_shading=ms)
     return si, desc, (0.5, 0.5, 0.98), (0.5, 0.42, 0.0)

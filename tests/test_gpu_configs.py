@@ -96,3 +96,42 @@ def test_c1_cornell_rendered_512x512_16spp():
     assert ol.same_bits(got, want)
     img = api.image_from_color_buffer(got, ns)
     assert img.shape == (512, 512, 3) and img.max() == 255 and 20 < img.mean() < 235
+
+
+def test_c3_metal_mesh_1080p():
+    """BASELINE.json configs[2] with a stand-in mesh (the Buddha .obj is not shipped): a 1 310 720-triangle displaced icosphere baked
+    through crt_bake_mesh as SMOOTH_TRIANGLE objects, gold METAL (Beckmann microfacet reflection, conductor Fresnel), QBVH,
+    sphere light + sky.  Parity on a 640 x 360 x 2 spp image against the oracle (>= 99.9 % of the pixels bit-identical: the
+    glossy lobes' exp / log allowance, tests/test_trace_pieces.py); then the configuration's 1920 x 1080 frame, 8 spp, timed,
+    with the same mean radiance."""
+    import time
+    gold = api.METALS["GOLD"]
+    si, desc, pos, look = scenes.smooth_blob_room(smooth=True, max_depth=5, rng_seed=23, mesh=scenes.icosphere(8),
+                                                  blob_material=api.material(api.MAT_METAL, gold[0], k=gold[1], uroughness=0.1))
+    assert si.num_obj > 1_000_000
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=True)
+    scene = api.Scene(built)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    small = api.make_film(cam, 1.2, 640, 360)
+    r = api.Renderer(scene, desc, cam, small)
+    r.render(2)
+    got, _ = r.read()
+    r.close()
+    want = ol.OracleScene(si, built=built).render(desc, cam, small, 0, 2, nthreads=THREADS)
+    assert np.isfinite(got).all() and got.max() > 0
+    same = (got == want).all(axis=2).mean()
+    assert same >= 0.999, same
+    full = api.make_film(cam, 1.2, 1920, 1080)
+    r = api.Renderer(scene, desc, cam, full)
+    r.render(1)
+    r.reset(0)
+    t0 = time.perf_counter()
+    r.render(8)
+    gpu_s = time.perf_counter() - t0
+    big, ns = r.read()
+    st = r.stats()
+    r.close(); scene.close()
+    print("C3 render: 1920x1080, 8 spp in %.3f s = %.1f samples/s/pixel; small image %.5f bit-identical" % (gpu_s, 8 / gpu_s, same))
+    assert ns == 8 and np.isfinite(big).all()
+    assert abs(big.mean() / 8 - got.mean() / 2) < 0.05 * (got.mean() / 2)
+    assert st["rays_shadow"] < st["rays_closest"]                   # the metal takes no direct-light sample
