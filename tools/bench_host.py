@@ -14,10 +14,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from craytracer_amd import api, scenes  # noqa: E402
 
-wl = sys.argv[1] if len(sys.argv) > 1 else "courtyard-10M"
+wl = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "courtyard-10M"
 n = 1 << 24
 si = scenes.courtyard(*bench.WORKLOADS[wl], seed=5)
-sc = api.Scene(api.BuiltScene(si, api.ACCEL_BVH4), 0)
+sc = api.Scene(api.BuiltScene(si, api.ACCEL_BVH4, sah="--reference-tree" not in sys.argv), 0)
 d_rays = bench.gen_incoherent_rays(sc, si, n, 0xC0FFEE, torch.device("cuda", 0))
 rays = d_rays.cpu().numpy()
 res = {"workload": wl, "rays": n}
