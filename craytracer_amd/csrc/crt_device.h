@@ -8,6 +8,10 @@
  * never fminf/fmaxf) because NaN and -0.0 operands must take the same branch as on the CPU.
  */
 #pragma once
+#ifndef CRT_OBJ_STRIDE
+#define CRT_OBJ_STRIDE 3                     /* float4 per object record: 48 bytes */
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/crt_gpu.h"
@@ -30,7 +34,7 @@
  */
 struct DevScene {
     const float4* nodes4;
-    const float4* objs;
+    const float4* objs;          /* CRT_OBJ_STRIDE float4 per object */
     const crt_shape* shapes;
     const float4* nodes2;
     const int* cell_start;
@@ -459,7 +463,7 @@ __device__ __noinline__ float dev_shape(const crt_shape* shapes, int si, const D
 template <bool TRI_ONLY>
 CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shadow, DHit* h)
 {
-    const float4* rec = sc.objs + (size_t)oi * 3;
+    const float4* rec = sc.objs + (size_t)oi * CRT_OBJ_STRIDE;
     float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     h->obj = __float_as_int(r2.y);
     h->part = 0;

@@ -328,7 +328,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
 
     try {
         /* object records (48 B) in final order */
-        std::vector<float4> objs((size_t)n * 3);
+        std::vector<float4> objs((size_t)n * CRT_OBJ_STRIDE);
         bool all_tri = true, accel_tri = true, accel_bounded = true;
         for (int i = 0; i < n; i++) {
             const int t = desc->obj_type[i], r = desc->obj_ref[i];
@@ -344,9 +344,9 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             }
             float idf, tf, rf;
             memcpy(&idf, &desc->obj_id[i], 4); memcpy(&tf, &t, 4); memcpy(&rf, &r, 4);
-            objs[(size_t)i*3 + 0] = make_float4(v[0], v[1], v[2], v[3]);
-            objs[(size_t)i*3 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-            objs[(size_t)i*3 + 2] = make_float4(v[8], idf, tf, rf);
+            objs[(size_t)i*CRT_OBJ_STRIDE + 0] = make_float4(v[0], v[1], v[2], v[3]);
+            objs[(size_t)i*CRT_OBJ_STRIDE + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            objs[(size_t)i*CRT_OBJ_STRIDE + 2] = make_float4(v[8], idf, tf, rf);
         }
         s->tri_only = all_tri;
         s->accel_tri_only = accel_tri;
