@@ -310,7 +310,7 @@ typedef struct crt_render_desc {
     const int32_t*      obj_material;    /* [num_obj] index into materials[] (getObjectMatPtr, shapes.cpp) */
     const crt_material* materials;
     int32_t             num_materials;
-    int32_t             has_env_light;   /* sl->env_light != NULL (lights.h EnvLight, type CONSTANT) */
+    int32_t             has_env_light;   /* sl->env_light != NULL (lights.h EnvLight, type CONSTANT); sampled as a light only when env_intensity > 0 (buildscene.h:525-533) */
     float               env_color[3];
     float               env_intensity;
     float               env_world_radius;/* EnvLight.world_radius as buildscene.h:836-872 computed it */
