@@ -15,6 +15,7 @@
 #include <vector>
 #include <new>
 #include <mutex>
+#include <atomic>
 
 namespace {
 
@@ -40,8 +41,25 @@ struct DeviceGuard {
 
 } // namespace
 
+/* Device memory a launch needs beyond the caller's rays and results. */
+struct Scratch {
+    unsigned* queue_head;     /* 256 B, word 0 used; zeroed on the launch stream before every launch */
+    unsigned* ovf_word; float* ovf_key; unsigned ovf_threads;   /* per-lane stack overflow, [CRT_OVF_DEPTH][ovf_threads] */
+    unsigned* bin_hist; unsigned* bin_cursor;                   /* ray binning: CRT_BIN_CELLS counters each */
+    unsigned* perm; size_t perm_cap;                            /* ray order, one word per ray */
+};
+
+/* Events of one launch.  A scene keeps a ring of them so that each caller can ask for the duration of
+ * ITS launch (crt_scene_last_kernel_ms) while other threads keep launching through the same scene. */
+#define CRT_TIMING_RING 16
+struct LaunchTiming { hipEvent_t ev_bin, ev_start, ev_stop; unsigned long long seq; bool binned; };
+
+#define CRT_OCC_CACHE 32
+struct OccEntry { const void* fn; int per_cu; };
+
 struct crt_scene {
     int device;
+    unsigned long long uid;   /* distinguishes scenes that reuse an address (thread-local launch tokens) */
     DevScene dev;
     bool tri_only;            /* every object is a triangle type */
     bool accel_tri_only;      /* every object below the accelerator is a triangle type */
@@ -53,22 +71,22 @@ struct crt_scene {
     /* device allocations */
     void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
     unsigned long long* d_counters;
-    unsigned* d_queue_head;   /* 256 B, word 0 used */
-    unsigned* d_ovf_word; float* d_ovf_key; unsigned ovf_threads;
-    hipEvent_t ev_bin, ev_start, ev_stop; bool ev_valid; bool last_binned;
+    Scratch own;              /* allocated by crt_scene_create (perm may grow) */
+    Scratch na;               /* a second set of scratch pointers a launch can be directed to (unused so far) */
+    LaunchTiming ring[CRT_TIMING_RING]; int ring_valid;   /* events created so far */
+    unsigned long long seq;   /* launches so far; launch k uses ring[k % CRT_TIMING_RING] */
+    OccEntry occ[CRT_OCC_CACHE]; int n_occ;               /* resident blocks per CU of each kernel, queried once */
     /* Every launch through this scene uses the one queue head and the one stack-overflow area, so
      * launches are ordered: a launch waits (on the device) for the previous one's ev_stop even when
      * it is enqueued on another stream.  The kernels are persistent and fill the GPU, so nothing
      * is lost by that.  `mu` guards the launch sequence and the events against concurrent callers. */
     std::mutex mu;
-    bool launched;
     /* host-buffer entry points: two chunk-sized device buffers and two streams, created on first use */
     void* d_chunk_in[2]; void* d_chunk_aux[2]; void* d_chunk_out[2]; void* d_chunk_out2[2];
     size_t chunk_cap;         /* rays per chunk buffer */
     /* ray binning (crt_binning.h): triangle-only QBVH scenes, batches of at least CRT_BIN_MIN_RAYS */
     unsigned root_word2;      /* BVH: root in k_bvh2's child-word form */
     bool binning; BinGrid bin_grid; bool bin_grid_valid;
-    unsigned* d_bin_hist; unsigned* d_bin_cursor; unsigned* d_perm; size_t perm_cap;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
 
@@ -116,6 +134,14 @@ int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
     if (d->accel < CRT_ACCEL_NONE || d->accel > CRT_ACCEL_BVH4) return CRT_E_INVALID;
     if (d->num_obj >= (1 << 28)) return CRT_E_TOOBIG;
     if (d->num_obj > 0 && (!d->obj_type || !d->obj_ref || !d->obj_id)) return CRT_E_INVALID;
+    {   /* obj_id is what crt_hit.obj reports and what callers index their per-object tables with: a permutation of 0..num_obj-1 */
+        std::vector<bool> seen((size_t)d->num_obj, false);
+        for (int i = 0; i < d->num_obj; i++) {
+            const int id = d->obj_id[i];
+            if (id < 0 || id >= d->num_obj || seen[(size_t)id]) return CRT_E_INVALID;
+            seen[(size_t)id] = true;
+        }
+    }
     for (int i = 0; i < d->num_obj; i++) {
         int t = d->obj_type[i], r = d->obj_ref[i];
         if (t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE) {
@@ -189,81 +215,99 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
-                     s->d_bnodes2, s->d_counters, s->d_queue_head, s->d_ovf_word, s->d_ovf_key,
-                     s->d_bin_hist, s->d_bin_cursor, s->d_perm };
+                     s->d_bnodes2, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
+                     s->own.bin_hist, s->own.bin_cursor, s->own.perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
         void* q[] = { s->d_chunk_in[k], s->d_chunk_aux[k], s->d_chunk_out[k], s->d_chunk_out2[k] };
         for (void* p : q) if (p) (void)hipFree(p);
         if (s->chunk_streams_valid) (void)hipStreamDestroy(s->chunk_stream[k]);
     }
-    if (s->ev_valid) { (void)hipEventDestroy(s->ev_bin); (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); }
+    for (int k = 0; k < s->ring_valid; k++) {
+        (void)hipEventDestroy(s->ring[k].ev_bin); (void)hipEventDestroy(s->ring[k].ev_start); (void)hipEventDestroy(s->ring[k].ev_stop);
+    }
     delete s;
 }
+
+std::atomic<unsigned long long> g_scene_uid(0);
+
+/* the calling thread's most recent launch: which scene, which launch number */
+thread_local unsigned long long tl_scene_uid = 0, tl_seq = 0;
 
 /* ---- launch ------------------------------------------------------------------------- */
 
 const unsigned CRT_BIN_MIN_RAYS = 1u << 18;
+const size_t CRT_PERM_PRESIZE = (size_t)1 << 24;      /* 64 MB: ray order for batches up to 2^24 rays, allocated with the scene */
 /* The walks saturate at 4 resident blocks (waves per SIMD) per CU: 691 / 936 / 1 090 / 1 092 Mrays/s at 2 / 3 / 4 / 5
  * (closest hit, courtyard-10M); the any-hit walk, whose 16 KB stack would allow 7, runs 1 904 at 5 against 1 869 at 7. */
 const int CRT_MAX_BLOCKS_PER_CU = 5;
 
+/* NOALLOC: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
+ * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before. */
 template <class K>
-int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false)
+int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false, bool noalloc = false)
 {
+    std::lock_guard<std::mutex> lock(s->mu);
+    Scratch& sx = noalloc ? s->na : s->own;
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CRT_BLOCK, 0));
-    if (per_cu < 1) per_cu = 1;
+    for (int k = 0; k < s->n_occ; k++) if (s->occ[k].fn == (const void*)kernel) per_cu = s->occ[k].per_cu;
+    if (per_cu == 0) {                                  /* once per kernel and scene, not once per launch */
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CRT_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        if (s->n_occ < CRT_OCC_CACHE) { s->occ[s->n_occ].fn = (const void*)kernel; s->occ[s->n_occ].per_cu = per_cu; s->n_occ++; }
+    }
     if (per_cu > CRT_MAX_BLOCKS_PER_CU) per_cu = CRT_MAX_BLOCKS_PER_CU;
     unsigned blocks = (unsigned)(s->num_cus * per_cu);
     unsigned need = (la.n + CRT_BLOCK - 1) / CRT_BLOCK;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (blocks * CRT_BLOCK > s->ovf_threads) blocks = s->ovf_threads / CRT_BLOCK;   /* overflow area is sized for this many */
-    la.queue_head = s->d_queue_head;
-    la.ovf_word = s->d_ovf_word;
-    la.ovf_key = s->d_ovf_key;
-    la.grid_threads = s->ovf_threads;
-    std::lock_guard<std::mutex> lock(s->mu);
-    if (s->launched) HIPCHK(hipStreamWaitEvent(stream, s->ev_stop, 0));     /* shared scratch: see crt_scene */
-    HIPCHK(hipMemsetAsync(s->d_queue_head, 0, 256, stream));
+    if (blocks * CRT_BLOCK > sx.ovf_threads) blocks = sx.ovf_threads / CRT_BLOCK;   /* overflow area is sized for this many */
+    la.queue_head = sx.queue_head;
+    la.ovf_word = sx.ovf_word;
+    la.ovf_key = sx.ovf_key;
+    la.grid_threads = sx.ovf_threads;
+    LaunchTiming& lt = s->ring[s->seq % CRT_TIMING_RING];
+    if (s->seq > 0) HIPCHK(hipStreamWaitEvent(stream, s->ring[(s->seq - 1) % CRT_TIMING_RING].ev_stop, 0));   /* shared scratch: see crt_scene */
+    const bool bin = use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
+    HIPCHK(hipMemsetAsync(sx.queue_head, 0, 256, stream));
     la.perm = 0;
-    s->last_binned = false;
-    if (use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS) {
-        if (la.n > s->perm_cap) {                     /* grows only; the previous launch has been waited for above */
-            HIPCHK(hipStreamSynchronize(stream));
-            if (s->d_perm) { (void)hipFree(s->d_perm); s->d_perm = 0; s->perm_cap = 0; }
-            if (!hip_ok(hipMalloc((void**)&s->d_perm, (size_t)la.n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
-            s->perm_cap = la.n;
+    if (bin) {
+        if (la.n > sx.perm_cap) {
+            if (noalloc) return CRT_E_TOOBIG;
+            HIPCHK(hipStreamSynchronize(stream));     /* grows only; the previous launch has been waited for above */
+            if (sx.perm) { (void)hipFree(sx.perm); sx.perm = 0; sx.perm_cap = 0; }
+            if (!hip_ok(hipMalloc((void**)&sx.perm, (size_t)la.n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
+            sx.perm_cap = la.n;
         }
-        HIPCHK(hipEventRecord(s->ev_bin, stream));
-        s->last_binned = true;
+        HIPCHK(hipEventRecord(lt.ev_bin, stream));
         const unsigned bb = (la.n + CRT_BIN_CHUNK - 1) / CRT_BIN_CHUNK;
-        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, s->d_bin_hist);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, s->d_bin_hist, s->d_bin_cursor);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, s->d_bin_cursor, s->d_perm);
+        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, sx.bin_hist);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, sx.bin_hist, sx.bin_cursor);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, sx.bin_cursor, sx.perm);
         HIPCHK(hipGetLastError());
-        la.perm = s->d_perm;
+        la.perm = sx.perm;
     }
-    HIPCHK(hipEventRecord(s->ev_start, stream));
+    HIPCHK(hipEventRecord(lt.ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->ev_stop, stream));
-    s->launched = true;
+    HIPCHK(hipEventRecord(lt.ev_stop, stream));
+    lt.binned = bin;
+    lt.seq = ++s->seq;
+    tl_scene_uid = s->uid; tl_seq = lt.seq;
     return CRT_OK;
 }
 
 template <bool TRI_ONLY, bool COUNT>
-int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st)
+int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na = false)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true)
-                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true);
-    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true);
-    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st);
-    default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st);
+    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
+                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
+    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
+    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st, false, na);
+    default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, false, na);
     }
 }
 template <bool TRI_ONLY, bool COUNT>
@@ -312,7 +356,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     if (!out) return CRT_E_INVALID;
     *out = 0;
     int d4 = 0, d2 = 0;
-    int rc = validate_desc(desc, &d4, &d2);
+    int rc;
+    try { rc = validate_desc(desc, &d4, &d2); } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
     if (rc != CRT_OK) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CRT_E_NODEVICE;
@@ -454,20 +499,30 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     int cus = 0;
     if (!hip_ok(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute")) { free_scene(s); return CRT_E_HIP; }
     s->num_cus = cus > 0 ? cus : 1;
-    s->ovf_threads = (unsigned)s->num_cus * 8u * CRT_BLOCK;           /* at most 8 resident 256-thread blocks per CU */
-    size_t ovf_bytes = (size_t)s->ovf_threads * CRT_OVF_DEPTH * sizeof(unsigned);
-    if (!hip_ok(hipMalloc((void**)&s->d_ovf_word, ovf_bytes), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_ovf_key, ovf_bytes), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_queue_head, 256), "hipMalloc") ||
+    s->own.ovf_threads = (unsigned)s->num_cus * 8u * CRT_BLOCK;       /* at most 8 resident 256-thread blocks per CU */
+    size_t ovf_bytes = (size_t)s->own.ovf_threads * CRT_OVF_DEPTH * sizeof(unsigned);
+    if (!hip_ok(hipMalloc((void**)&s->own.ovf_word, ovf_bytes), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->own.ovf_key, ovf_bytes), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->own.queue_head, 256), "hipMalloc") ||
         !hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_bin_hist, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_bin_cursor, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
-    if (!hip_ok(hipMemset(s->d_bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
-    if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset") ||
-        !hip_ok(hipEventCreate(&s->ev_start), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
-    if (!hip_ok(hipEventCreate(&s->ev_stop), "hipEventCreate")) { (void)hipEventDestroy(s->ev_start); free_scene(s); return CRT_E_HIP; }
-    if (!hip_ok(hipEventCreate(&s->ev_bin), "hipEventCreate")) { (void)hipEventDestroy(s->ev_start); (void)hipEventDestroy(s->ev_stop); free_scene(s); return CRT_E_HIP; }
-    s->ev_valid = true;
+        !hip_ok(hipMalloc((void**)&s->own.bin_hist, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&s->own.bin_cursor, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    if (s->bin_grid_valid) {
+        /* ray order sized ahead for the batches the binning is meant for, so that the launch path neither allocates
+         * nor synchronises; a larger batch still grows it (launch()) */
+        s->own.perm_cap = CRT_PERM_PRESIZE;
+        if (!hip_ok(hipMalloc((void**)&s->own.perm, s->own.perm_cap * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    }
+    if (!hip_ok(hipMemset(s->own.bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset") ||
+        !hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
+    for (int k = 0; k < CRT_TIMING_RING; k++) {
+        LaunchTiming& lt = s->ring[k];
+        if (!hip_ok(hipEventCreate(&lt.ev_bin), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
+        if (!hip_ok(hipEventCreate(&lt.ev_start), "hipEventCreate")) { (void)hipEventDestroy(lt.ev_bin); free_scene(s); return CRT_E_HIP; }
+        if (!hip_ok(hipEventCreate(&lt.ev_stop), "hipEventCreate")) { (void)hipEventDestroy(lt.ev_bin); (void)hipEventDestroy(lt.ev_start); free_scene(s); return CRT_E_HIP; }
+        s->ring_valid = k + 1;
+    }
+    s->uid = ++g_scene_uid;
 
     DevScene& dv = s->dev;
     dv.nodes4 = (const float4*)s->d_nodes4;
@@ -530,7 +585,7 @@ int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
     return CRT_OK;
 }
 
-int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
+static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc)
 {
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -541,8 +596,13 @@ int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_h
     memset(&la, 0, sizeof la);
     la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n;
     hipStream_t st = (hipStream_t)stream;
-    if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st) : dispatch_closest<true, false>(s, la, st);
-    return s->count ? dispatch_closest<false, true>(s, la, st) : dispatch_closest<false, false>(s, la, st);
+    if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st, noalloc) : dispatch_closest<true, false>(s, la, st, noalloc);
+    return s->count ? dispatch_closest<false, true>(s, la, st, noalloc) : dispatch_closest<false, false>(s, la, st, noalloc);
+}
+
+int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
+{
+    return intersect_dev(s, d_rays, n, d_hits, stream, false);
 }
 
 int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
@@ -746,17 +806,29 @@ int crt_scene_reset_counters(crt_scene* s)
     HIPCHK(hipMemset(s->d_counters, 0, 256));
     return CRT_OK;
 }
+/* The calling thread's most recent launch through `s`: its slot of the timing ring, if it is still there. */
+static int my_timing(crt_scene* s, LaunchTiming** out)
+{
+    if (tl_scene_uid != s->uid || tl_seq == 0 || tl_seq > s->seq) return CRT_E_INVALID;     /* this thread has not launched through s */
+    if (s->seq - tl_seq >= CRT_TIMING_RING) return CRT_E_INVALID;                          /* overwritten by later launches */
+    LaunchTiming& lt = s->ring[(tl_seq - 1) % CRT_TIMING_RING];
+    if (lt.seq != tl_seq) return CRT_E_INVALID;
+    *out = &lt;
+    return CRT_OK;
+}
 int crt_scene_last_binning_ms(crt_scene* s, float* ms)
 {
     if (!s || !ms) return CRT_E_INVALID;
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     std::lock_guard<std::mutex> lock(s->mu);
-    if (!s->launched) return CRT_E_INVALID;
+    LaunchTiming* lt = 0;
+    int rc = my_timing(s, &lt);
+    if (rc != CRT_OK) return rc;
     *ms = 0.0f;
-    if (!s->last_binned) return CRT_OK;
-    HIPCHK(hipEventSynchronize(s->ev_start));
-    HIPCHK(hipEventElapsedTime(ms, s->ev_bin, s->ev_start));
+    if (!lt->binned) return CRT_OK;
+    HIPCHK(hipEventSynchronize(lt->ev_start));
+    HIPCHK(hipEventElapsedTime(ms, lt->ev_bin, lt->ev_start));
     return CRT_OK;
 }
 int crt_scene_last_kernel_ms(crt_scene* s, float* ms)
@@ -765,9 +837,11 @@ int crt_scene_last_kernel_ms(crt_scene* s, float* ms)
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     std::lock_guard<std::mutex> lock(s->mu);
-    if (!s->launched) return CRT_E_INVALID;
-    HIPCHK(hipEventSynchronize(s->ev_stop));
-    HIPCHK(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
+    LaunchTiming* lt = 0;
+    int rc = my_timing(s, &lt);
+    if (rc != CRT_OK) return rc;
+    HIPCHK(hipEventSynchronize(lt->ev_stop));
+    HIPCHK(hipEventElapsedTime(ms, lt->ev_start, lt->ev_stop));
     return CRT_OK;
 }
 

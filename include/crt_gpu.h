@@ -447,8 +447,10 @@ int  crt_scene_enable_counters(crt_scene* s, int on);
 int  crt_scene_get_counters(crt_scene* s, crt_counters* out);   /* syncs the device */
 int  crt_scene_reset_counters(crt_scene* s);
 
-/* Duration in milliseconds of the most recent traversal kernel launched through this
- * scene, measured with HIP events on the stream it was launched on (syncs). */
+/* Duration in milliseconds of the traversal kernel of the CALLING THREAD's most recent launch through this
+ * scene, measured with HIP events on the stream it was launched on (syncs on that launch).  Each launch has
+ * its own events (a ring of 16 per scene), so concurrent callers read their own timings; CRT_E_INVALID when
+ * the thread has not launched through `s` or 16 later launches have reused the slot. */
 int  crt_scene_last_kernel_ms(crt_scene* s, float* ms);
 /* Duration of the ray-binning kernels that preceded it (0 when the launch did not bin). */
 int  crt_scene_last_binning_ms(crt_scene* s, float* ms);

@@ -148,3 +148,20 @@ def test_grid_cells(built):
     d = clone(b.desc)
     d.cell_start = None
     assert create(d) == INVALID
+
+
+def test_object_ids_must_be_a_permutation(built):
+    """crt_hit.obj indexes the caller's per-object tables (materials, shading records): an id outside
+    [0, num_obj) or one that appears twice is refused before anything reaches a kernel."""
+    b = built["mixed"]
+    n = b.desc.num_obj
+    for pos, bad in ((0, n), (n // 2, -1), (n - 1, 10 ** 6), (1, int(b.obj_id[0]))):      # out of range x3, duplicate
+        ids = b.obj_id.copy()
+        ids[pos] = bad
+        d = clone(b.desc)
+        d.obj_id = ids.ctypes.data
+        assert create(d) == INVALID, (pos, bad)
+    ids = b.obj_id.copy()                                                               # any permutation is fine
+    d = clone(b.desc)
+    d.obj_id = ids[::-1].copy().ctypes.data
+    assert create(d) not in (INVALID, TOOBIG)
