@@ -22,6 +22,7 @@ ACCEL_NONE, ACCEL_GRID, ACCEL_BVH, ACCEL_BVH4 = range(4)
 ACCEL_NAMES = {"NONE": ACCEL_NONE, "GRID": ACCEL_GRID, "BVH": ACCEL_BVH, "BVH4": ACCEL_BVH4}
 TRAVERSE_AUTO, TRAVERSE_PRUNED, TRAVERSE_EXACT = range(3)
 BUILD_SAH = 1
+NOALLOC_MAX_RAYS = 1 << 22
 TRI_TYPES = (TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE)
 
 K_EPSILON = np.float32(0.000007)
@@ -147,7 +148,7 @@ EXPORTS = [
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
-    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev",
+    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
@@ -202,6 +203,7 @@ def lib():
     L.crt_shadow_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.crt_intersect_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.crt_shadow_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.crt_intersect_batch_dev_noalloc.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.crt_scene_enable_counters.argtypes = [vp, C.c_int]
     L.crt_scene_get_counters.argtypes = [vp, C.POINTER(CrtCounters)]
     L.crt_scene_reset_counters.argtypes = [vp]
@@ -707,6 +709,10 @@ class Scene:
     def intersect_dev(self, d_rays, n, d_hits, stream=None):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
         _check(lib().crt_intersect_batch_dev(self._h, d_rays, n, d_hits, stream), "crt_intersect_batch_dev")
+
+    def intersect_dev_noalloc(self, d_rays, n, d_hits, stream=None):
+        """crt_intersect_batch_dev_noalloc: the same on the library's file-scope scratch array (n <= NOALLOC_MAX_RAYS)."""
+        _check(lib().crt_intersect_batch_dev_noalloc(self._h, d_rays, n, d_hits, stream), "crt_intersect_batch_dev_noalloc")
 
     def shadow_dev(self, d_rays, d_light_dist, n, d_t, d_occ, stream=None):
         _check(lib().crt_shadow_batch_dev(self._h, d_rays, d_light_dist, n, d_t, d_occ, stream), "crt_shadow_batch_dev")

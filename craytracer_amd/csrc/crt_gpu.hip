@@ -72,7 +72,7 @@ struct crt_scene {
     void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
     unsigned long long* d_counters;
     Scratch own;              /* allocated by crt_scene_create (perm may grow) */
-    Scratch na;               /* a second set of scratch pointers a launch can be directed to (unused so far) */
+    Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
     LaunchTiming ring[CRT_TIMING_RING]; int ring_valid;   /* events created so far */
     unsigned long long seq;   /* launches so far; launch k uses ring[k % CRT_TIMING_RING] */
     OccEntry occ[CRT_OCC_CACHE]; int n_occ;               /* resident blocks per CU of each kernel, queried once */
@@ -229,7 +229,55 @@ void free_scene(crt_scene* s)
     delete s;
 }
 
+/* ---- file-scope scratch of the allocation-free entry point ----------------------------
+ * crt_intersect_batch_dev_noalloc may not allocate, so the device memory its kernels need beyond the
+ * caller's rays and hits lives in one file-scope device array.  Every GPU the library runs on holds its
+ * own copy at its own address until the process ends; the array's NAME is a host-side stand-in, not a
+ * device address, so host code only ever uses the pointer hipGetSymbolAddress returned for the device
+ * (resolved once per device in crt_scene_create, with that device current).
+ *   [0, 256)                       queue head
+ *   [256, +CRT_BIN_CELLS * 4)      binning histogram     (zeroed with the queue head before every launch)
+ *   [.., +CRT_BIN_CELLS * 4)       binning cursors
+ *   [.., +CRT_NA_MAX_RAYS * 4)     ray order (perm)
+ *   [.., +2 x CRT_NA_THREADS * CRT_OVF_DEPTH * 4)   per-lane stack overflow (words, keys)
+ * = 64 MiB + 33 024 B. */
+#define CRT_NA_MAX_RAYS  CRT_NOALLOC_MAX_RAYS         /* include/crt_gpu.h: 2^22 */
+#define CRT_NA_THREADS   (512u * CRT_BLOCK)               /* 512 resident blocks: 2 per CU on 256 CUs */
+#define CRT_NA_OFF_HIST  256u
+#define CRT_NA_OFF_CURS  (CRT_NA_OFF_HIST + CRT_BIN_CELLS * 4u)
+#define CRT_NA_OFF_PERM  (CRT_NA_OFF_CURS + CRT_BIN_CELLS * 4u)
+#define CRT_NA_OFF_OVFW  (CRT_NA_OFF_PERM + CRT_NA_MAX_RAYS * 4u)
+#define CRT_NA_OFF_OVFK  (CRT_NA_OFF_OVFW + CRT_NA_THREADS * CRT_OVF_DEPTH * 4u)
+#define CRT_NA_BYTES     (CRT_NA_OFF_OVFK + CRT_NA_THREADS * CRT_OVF_DEPTH * 4u)
+static_assert(CRT_NA_BYTES == CRT_NOALLOC_SCRATCH_BYTES, "include/crt_gpu.h states the size of the scratch array");
+static __device__ __align__(256) unsigned char scratch[CRT_NA_BYTES];
+
+#define CRT_MAX_DEVICES 64
+std::mutex g_na_mu;
+unsigned char* g_na_ptr[CRT_MAX_DEVICES];                  /* per device: address of ITS copy of `scratch` */
 std::atomic<unsigned long long> g_scene_uid(0);
+
+/* call with `device` current */
+int resolve_noalloc_scratch(int device, Scratch* out)
+{
+    if (device < 0 || device >= CRT_MAX_DEVICES) return CRT_E_TOOBIG;
+    std::lock_guard<std::mutex> lock(g_na_mu);
+    if (!g_na_ptr[device]) {
+        void* ptr = 0;
+        if (!hip_ok(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !ptr) return CRT_E_HIP;
+        g_na_ptr[device] = (unsigned char*)ptr;
+    }
+    unsigned char* base = g_na_ptr[device];
+    out->queue_head = (unsigned*)base;
+    out->bin_hist = (unsigned*)(base + CRT_NA_OFF_HIST);
+    out->bin_cursor = (unsigned*)(base + CRT_NA_OFF_CURS);
+    out->perm = (unsigned*)(base + CRT_NA_OFF_PERM);
+    out->perm_cap = CRT_NA_MAX_RAYS;
+    out->ovf_word = (unsigned*)(base + CRT_NA_OFF_OVFW);
+    out->ovf_key = (float*)(base + CRT_NA_OFF_OVFK);
+    out->ovf_threads = CRT_NA_THREADS;
+    return CRT_OK;
+}
 
 /* the calling thread's most recent launch: which scene, which launch number */
 thread_local unsigned long long tl_scene_uid = 0, tl_seq = 0;
@@ -269,7 +317,10 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
     LaunchTiming& lt = s->ring[s->seq % CRT_TIMING_RING];
     if (s->seq > 0) HIPCHK(hipStreamWaitEvent(stream, s->ring[(s->seq - 1) % CRT_TIMING_RING].ev_stop, 0));   /* shared scratch: see crt_scene */
     const bool bin = use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
-    HIPCHK(hipMemsetAsync(sx.queue_head, 0, 256, stream));
+    /* what must start at zero: the queue head, and (the binning kernels leave it zeroed, but a launch that
+     * failed half way may not have) the histogram behind it in the file-scope array */
+    if (noalloc) HIPCHK(hipMemsetAsync(sx.queue_head, 0, CRT_NA_OFF_CURS, stream));
+    else HIPCHK(hipMemsetAsync(sx.queue_head, 0, 256, stream));
     la.perm = 0;
     if (bin) {
         if (la.n > sx.perm_cap) {
@@ -522,6 +573,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         if (!hip_ok(hipEventCreate(&lt.ev_stop), "hipEventCreate")) { (void)hipEventDestroy(lt.ev_bin); (void)hipEventDestroy(lt.ev_start); free_scene(s); return CRT_E_HIP; }
         s->ring_valid = k + 1;
     }
+    /* this GPU's copy of the file-scope scratch array (crt_intersect_batch_dev_noalloc), device `device` is current */
+    if ((rc = resolve_noalloc_scratch(device, &s->na)) != CRT_OK) { free_scene(s); return rc; }
     s->uid = ++g_scene_uid;
 
     DevScene& dv = s->dev;
@@ -590,6 +643,7 @@ static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit*
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
     if (n > 0xF0000000u) return CRT_E_TOOBIG;                        /* 32-bit queue head; waves claim 64 slots at a time past the end */
+    if (noalloc && n > CRT_NA_MAX_RAYS) return CRT_E_TOOBIG;         /* the file-scope scratch holds the order of this many rays */
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     LaunchArgs la;
@@ -603,6 +657,12 @@ static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit*
 int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
 {
     return intersect_dev(s, d_rays, n, d_hits, stream, false);
+}
+
+/* The same kernels on the file-scope scratch array: no hipMalloc / hipFree / allocating call on this path. */
+int crt_intersect_batch_dev_noalloc(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
+{
+    return intersect_dev(s, d_rays, n, d_hits, stream, true);
 }
 
 int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,

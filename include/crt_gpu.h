@@ -226,6 +226,21 @@ int  crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_
 int  crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                           float* d_t_out, uint8_t* d_occluded_out, void* stream);
 
+/* crt_intersect_batch_dev for callers that cannot allocate.  No counterpart in the reference: it exists for
+ * callers that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same kernels, same results bit for bit; the device memory they need beyond d_rays / d_hits (queue
+ * head, ray order of the binning step, per-lane stack overflow) is one file-scope device array of
+ * CRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, instead of the
+ * scene's own buffers.  The call performs no hipMalloc / hipFree / allocating library call.
+ *   n > CRT_NOALLOC_MAX_RAYS              -> CRT_E_TOOBIG
+ *   resident grid capped at 512 workgroups (the overflow part of the array is sized for that many)
+ * Calls through ONE crt_scene are ordered by the library like crt_intersect_batch_dev's.  All scenes on a GPU share
+ * that GPU's array (within a process): calls through DIFFERENT scenes that overlap in time on one GPU race on
+ * it -- the caller orders them. */
+#define CRT_NOALLOC_MAX_RAYS      (1u << 22)
+#define CRT_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u + 33024u)
+int  crt_intersect_batch_dev_noalloc(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream);
+
 /* ---- primary rays ------------------------------------------- */
 /* Camera (camera.h:14-26) without its sample table, and the Film fields the ray set-up reads
  * (camera.h:44-52).  Same field meaning as the reference. */
