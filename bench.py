@@ -10,8 +10,15 @@ bounces") on the procedural stand-in scenes.courtyard (the real asset is not shi
 fetched): 10 485 772 world-space triangles, QBVH built with the reference's rules, ray set
 R-incoherent = shuffled bounce-1..3 cosine-hemisphere rays.
 
-Multi-GPU: one process per GPU, full scene replica per GPU, each rank traces its own 2^24-ray batch
-(weak scaling, no data-path collective -- rays are independent); timing = max over ranks.
+Multi-GPU: one process per GPU, full scene replica per GPU, no data-path collective (rays are
+independent).  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a launcher:
+it starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) before
+anything touches the GPU and relays rank 0's JSON line; under torchrun the ranks are already there.
+Two ways of sharing the work, both in every N > 1 line:
+  weak   (`value`, the contract's default) each rank traces its own 2^24-ray batch;
+  strong one 2^24-ray batch cut into N contiguous slices (shard.shard_range), Mrays/s = 2^24 / max_i(time_i)
+         (`--scaling strong` makes this one `value` and the weak figure the second key).
+Timing = max over ranks, barrier + synchronize either side.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 Nothing here reads /root/reference.
@@ -27,7 +34,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 
 WORKLOADS = {
     # name: (n_copies, n_lat, n_lon) -> 2*n_lat*n_lon*n_copies + 12 triangles
@@ -128,7 +136,7 @@ def gen_shadow_rays(sc, si, d_rays, seed, device):
     return rays, ld.float().contiguous()
 
 
-def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, barrier, n_copies, n_lat, n_lon):
+def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, red_device, barrier, n_copies, n_lat, n_lon):
     import torch.distributed as dist
     width, height, depth, spp = 3840, 2160, 5, args.render_spp
     si, desc, pos, look = scenes.courtyard_render(n_copies, n_lat, n_lon, seed=5, max_depth=depth, rng_seed=1)
@@ -144,7 +152,7 @@ def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device,
     # rank k renders samples [k*spp, (k+1)*spp) of the one image; RCCL all-reduce of the colour buffers (world > 1)
     d_img, total_spp = shard.render_sharded(r, spp, rank, world, device)
     barrier()
-    dt = shard.max_over_ranks(time.perf_counter() - t0, device)
+    dt = shard.max_over_ranks(time.perf_counter() - t0, red_device)
     s1 = r.stats()
     rays = (s1["rays_closest"] - s0["rays_closest"]) + (s1["rays_shadow"] - s0["rays_shadow"])
     mean = float(d_img.mean().item()) / total_spp
@@ -155,29 +163,96 @@ def render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device,
            "traversal_kernel_fraction": round(((s1["ms_extend"] - s0["ms_extend"]) + (s1["ms_shadow"] - s0["ms_shadow"]))
                                               / (s1["ms_total"] - s0["ms_total"]), 3),
            "rays_per_sample_per_pixel": round(rays / spp / (width * height), 3), "mean_radiance": round(mean, 5),
-           "reduce": "RCCL all_reduce of the colour buffers" if world > 1 else "none (1 GPU)"}
+           "reduce": ("RCCL all_reduce of the colour buffers" if args.dist_backend == "nccl" else "gloo all_reduce of host copies (rehearsal)")
+           if world > 1 else "none (1 GPU)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as ol
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        w2, h2 = 256, 144
+        w2, h2, spp2 = 256, 144, args.render_cpu_spp       # sized for a few seconds of oracle time, not 0.2 s
         flm2 = api.make_film(cam, 1.0, w2, h2)
         o = ol.OracleScene(si, built=built)
         t1 = time.perf_counter()
-        want = o.render(desc, cam, flm2, 0, 2, nthreads=cores)
+        want = o.render(desc, cam, flm2, 0, spp2, nthreads=cores)
         cpu_s = time.perf_counter() - t1
         r2 = api.Renderer(sc, desc, cam, flm2)
-        r2.render(2)
+        r2.render(spp2)
         got, _ = r2.read()
         r2.close()
-        res["cpu_baseline"] = {"value": round(2 * w2 * h2 / cpu_s / (width * height), 5), "unit": "samples/s/pixel at %dx%d" % (width, height),
-                               "cores": cores, "kind": "port", "sample": "%dx%d image, 2 spp, oracle_render, %.1f s" % (w2, h2, cpu_s),
+        res["cpu_baseline"] = {"value": round(spp2 * w2 * h2 / cpu_s / (width * height), 5), "unit": "samples/s/pixel at %dx%d" % (width, height),
+                               "cores": cores, "kind": "port", "sample": "%dx%d image, %d spp, oracle_render, %.1f s" % (w2, h2, spp2, cpu_s),
                                "gpu_image_bit_identical_on_sample": bool((got == want).all())}
         o.close()
     r.close()
     sc.close()
     built.close()
     return res
+
+
+def src_hash():
+    """Hash of the sources that decide the walk kernels' memory traffic: a profiles/traffic.json entry measured on
+    other sources is stale and is not reported."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("crt_kernels.h", "crt_device.h", "crt_binning.h", "crt_build.cpp"):
+        h.update(open(os.path.join(ROOT, "craytracer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def spawn_ranks(n_gpus, argv):
+    """--gpus N without a launcher: start N rank processes of this script (fresh interpreters: this process has
+    not imported torch or touched HIP and never will), relay rank 0's output, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+def dry_run(args, rank, world):
+    """--dry-backend gloo: the multi-process plumbing of this script (rendezvous, slices, barriers, max-over-ranks
+    timing, rank 0's single JSON line) with NO ray traced and no GPU touched -- the seam tests/test_bench_launch.py
+    drives on CPU.  It measures nothing and says so."""
+    import torch
+    import torch.distributed as dist
+    from craytracer_amd import shard
+    if world > 1:
+        dist.init_process_group(args.dry_backend)
+    n = args.rays
+    b, e = shard.shard_range(n, rank, world)
+    slices = [None] * world
+    if world > 1:
+        dist.all_gather_object(slices, (rank, b, e))
+        dist.barrier()
+    else:
+        slices = [(rank, b, e)]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    buf = torch.full((4,), float(rank + 1))
+    buf, spp = shard.combine_radiance(buf, 3)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: launch plumbing only, nothing traced", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+                          "higher_is_better": True, "scaling": args.scaling, "dry": True, "backend": args.dry_backend,
+                          "slices": sorted(slices), "combined_radiance": buf.tolist(), "combined_spp": spp}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -200,10 +275,30 @@ def main():
                     help="skip the leg that repeats the batch on the reference's median-split tree (profiling runs: it launches "
                          "the same kernel, so per-kernel profile averages would mix the two trees)")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
-    ap.add_argument("--render-spp", type=int, default=4)
+    ap.add_argument("--render-spp", type=int, default=32, help="samples per pixel per GPU timed in the render leg")
+    ap.add_argument("--render-cpu-spp", type=int, default=24, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank its own batch (value), strong = one batch cut into N slices (value); the other one is "
+                         "reported under its own key")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the default) or gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks "
+                         "(ranks share devices round-robin; RCCL refuses two ranks on one GPU, gloo reduces host copies)")
+    ap.add_argument("--dry-backend", default=None, choices=["gloo"],
+                    help="test seam: run the launch / rendezvous / slicing / timing plumbing over this CPU backend, trace nothing")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])       # before anything imports torch / initialises HIP
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (pass --gpus N under a launcher with N ranks)" % (world, args.gpus))
+    if args.dry_backend:
+        return dry_run(args, rank, world)
     if args.builder is None:
         args.builder = "sah" if args.accel == "bvh4" else "reference"
     if args.builder == "sah" and args.accel != "bvh4":
@@ -212,17 +307,21 @@ def main():
     import torch
     from craytracer_amd import api, scenes, shard
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the traversal path")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
+    if world > 1:
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_device = device if args.dist_backend == "nccl" else "cpu"     # where the timing scalars are reduced
 
     # ---- scene (full replica per GPU) ----
     t0 = time.time()
@@ -235,22 +334,42 @@ def main():
     build_s = time.time() - t0
     n_tris = si.num_obj
 
-    # ---- rays: this rank's own batch, resident in HBM ----
+    # ---- rays, resident in HBM.  `own` = this rank's batch (weak scaling; seed + rank); `shared` = the one batch every
+    #      rank derives identically and traces a slice of (strong scaling).  At N = 1 they are the same batch. ----
     n = args.rays
-    d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
-    d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
     shadow = args.mode == "shadow"
+    d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
+    d_ld = None
     if shadow:
         d_rays, d_ld = gen_shadow_rays(sc, si, d_rays, 0xBEEF + rank, device)
-        d_t = torch.empty(n, dtype=torch.float32, device=device)
-        d_occ = torch.empty(n, dtype=torch.uint8, device=device)
-
-    def step():
+    if world > 1 and rank != 0:
+        d_shared = gen_incoherent_rays(sc, si, n, 0xC0FFEE, device)
+        d_shared_ld = None
         if shadow:
-            sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), n, d_t.data_ptr(), d_occ.data_ptr(), stream)
+            d_shared, d_shared_ld = gen_shadow_rays(sc, si, d_shared, 0xBEEF, device)
+    else:
+        d_shared, d_shared_ld = d_rays, d_ld
+    lo_s, hi_s = shard.shard_range(n, rank, world)                 # this rank's slice of the shared batch
+    d_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
+    d_t = torch.empty(n, dtype=torch.float32, device=device) if shadow else None
+    d_occ = torch.empty(n, dtype=torch.uint8, device=device) if shadow else None
+
+    def trace(rays, ld, first, count):
+        """one pass of the hot path over rays[first : first + count] (device pointers into the resident batch)"""
+        if count == 0:
+            return
+        rp = rays.data_ptr() + first * 24
+        if shadow:
+            sc.shadow_dev(rp, ld.data_ptr() + first * 4, count, d_t.data_ptr() + first * 4, d_occ.data_ptr() + first, stream)
         else:
-            sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream)
+            sc.intersect_dev(rp, count, d_hits.data_ptr() + first * 20, stream)
+
+    def step_weak():
+        trace(d_rays, d_ld, 0, n)
+
+    def step_strong():
+        trace(d_shared, d_shared_ld, lo_s, hi_s - lo_s)
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,37 +377,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step_fn, steps, warmup, with_kernel_ms):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; max over ranks."""
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        k_ms, b_ms = [], []
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+            if with_kernel_ms:
+                k_ms.append(sc.last_kernel_ms())       # HIP events on the launch stream (syncs the step)
+                b_ms.append(sc.last_binning_ms())
+        barrier()
+        return shard.max_over_ranks(time.perf_counter() - t_start, red_device), k_ms, b_ms
+
     # per-ray traversal statistics (defines the algorithmic bytes), outside the timed region
     sc.enable_counters(True)
     sc.reset_counters()
-    step()
+    step_weak()
     cnt = sc.counters()
     sc.enable_counters(False)
     nodes_per_ray = cnt["nodes_visited"] / n
     tris_per_ray = cnt["prims_tested"] / n
-    # 24 (ray in) + 20 (hit out) + one QBVH node per visit + 36 + 4 per triangle tested.
-    # A node visit reads 112 of the node's 128 bytes (6 plane rows + the child words; the axis byte
-    # travels in the parent's child word), so 112 is what is charged, not SURVEY's planning value 128.
     io_bytes = 28 + 5 if shadow else 24 + 20          # shadow: ray + light_dist in, t + occluded out
-    if args.accel == "bvh4":
-        bytes_per_ray = io_bytes + 112 * nodes_per_ray + 40 * tris_per_ray
-    elif args.accel == "bvh":                          # 32-byte nodes
-        bytes_per_ray = io_bytes + 32 * nodes_per_ray + 40 * tris_per_ray
-    else:                                              # grid: nodes_visited counts cells walked; 8 B of cell_start
-        bytes_per_ray = io_bytes + 8 * nodes_per_ray + 44 * tris_per_ray   # + 4 B item index per object tested
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms, bin_ms = [], []
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(sc.last_kernel_ms())      # HIP events on the launch stream (syncs the step)
-        bin_ms.append(sc.last_binning_ms())
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    elapsed = shard.max_over_ranks(elapsed, device)
+    def algorithmic_bytes(nodes, tris):
+        """SURVEY.md 8(d), NO-CACHE model: every node visit and every triangle test charged as if it came from HBM.
+        24 (ray in) + 20 (hit out) + one QBVH node per visit + 36 + 4 per triangle tested; a node visit reads 112 of
+        the node's 128 bytes (6 plane rows + the child words), so 112 is charged, not SURVEY's planning value 128."""
+        if args.accel == "bvh4":
+            return io_bytes + 112 * nodes + 40 * tris
+        if args.accel == "bvh":                        # 32-byte nodes
+            return io_bytes + 32 * nodes + 40 * tris
+        return io_bytes + 8 * nodes + 44 * tris        # grid: nodes = cells walked, 8 B of cell_start; + 4 B item index per object
+
+    bytes_per_ray = algorithmic_bytes(nodes_per_ray, tris_per_ray)
+
+    strong_is_value = args.scaling == "strong" and world > 1
+    elapsed, kernel_ms, bin_ms = timed(step_strong if strong_is_value else step_weak, args.steps, args.warmup, True)
+    rays_per_step = float(n) if strong_is_value else float(n) * world
+    value = rays_per_step * args.steps / elapsed / 1e6
+    other = None
+    if world > 1:                                      # the other way of sharing the work: fewer launches, own key
+        o_steps = max(2, min(args.steps, 5))
+        o_el, _, _ = timed(step_weak if strong_is_value else step_strong, o_steps, 1, False)
+        o_rays = float(n) * world if strong_is_value else float(n)
+        other = {"scaling": "weak" if strong_is_value else "strong", "value": round(o_rays * o_steps / o_el / 1e6, 3), "unit": "Mrays/s",
+                 "steps": o_steps, "ms_per_step": round(o_el / o_steps * 1e3, 4),
+                 "rays_per_step_all_gpus": int(o_rays)}
+        step_weak()                                    # leave d_hits holding this rank's own batch for the checks below
+        torch.cuda.synchronize()
+    elif strong_is_value:
+        pass
     if shadow:
         hit_frac = float(d_occ.float().mean().item())
         checksum = int(d_t.view(torch.int32).to(torch.int64).sum().item() + d_occ.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF
@@ -298,53 +439,73 @@ def main():
 
     gpu_hits_host = None if shadow else d_hits.cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
     host_rays_keep = d_rays.cpu().numpy()
-    total_rays = float(n) * world * args.steps
-    value = total_rays / elapsed / 1e6
     avg_kernel_ms = float(np.mean(kernel_ms))
-    achieved_gbs = bytes_per_ray * n / (avg_kernel_ms * 1e-3) / 1e9
+    rays_per_launch = (hi_s - lo_s) if strong_is_value else n
+    props = torch.cuda.get_device_properties(device)
+    clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+    shash = src_hash()
+    traffic_db = {}
+    try:
+        traffic_db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        pass
 
+    def roofline(kernel_name, kernel_ms_, binning_ms_, nodes, tris, key, chk, n_launch):
+        """HBM roofline of one walk-kernel launch.  `achieved` / `frac` are the COUNTER-based HBM-side figure (PMC passes of
+        this same command, profiles/traffic.json; an entry counts only if it was measured on these sources, this workload and
+        these hit records -- else traffic is null and so is frac).  The SURVEY 8(d) algorithmic bytes are reported beside it
+        under `algorithmic`, labelled as the no-cache model they are: L2 serves about half the lines, so that figure divided by
+        the kernel time is NOT a rate any memory level sustains and is not compared with a peak."""
+        bpr = algorithmic_bytes(nodes, tris)
+        rf = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+              "kernel": kernel_name, "kernel_ms": round(kernel_ms_, 4), "binning_ms": round(binning_ms_, 4),
+              "algorithmic": {"model": "no-cache", "bytes_per_ray": round(bpr, 2), "bytes_per_launch": int(bpr * n_launch),
+                              "gbs_if_nothing_were_cached": round(bpr * n_launch / (kernel_ms_ * 1e-3) / 1e9, 1),
+                              "nodes_per_ray": round(nodes, 3), "tris_per_ray": round(tris, 3)}}
+        tr = traffic_db.get(key)
+        if tr and tr.get("rays") == n_launch and tr.get("src_hash") == shash and tr.get("hits_checksum") == chk and args.binning == "on":
+            t = tr["hbm_bytes_per_launch"]
+            gbs = t / (kernel_ms_ * 1e-3) / 1e9
+            rf.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": t,
+                       "traffic_over_algorithmic": round(t / (bpr * n_launch), 3), "traffic_source": tr.get("source"),
+                       "hbm_achievable_gbs": 6300.0, "frac_of_achievable": round(gbs / 6300.0, 4)})
+            if tr.get("l2_requests_per_launch"):
+                l2 = tr["l2_requests_per_launch"] * 128.0 / (kernel_ms_ * 1e-3) / 1e9
+                rf["l2"] = {"achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
+                            "hit_rate": tr.get("l2_hit_rate"), "requests_per_launch": tr["l2_requests_per_launch"]}
+            if tr.get("tcp_lane_accesses_per_launch"):
+                # per-CU L1 (TCP) access rate against the 1.0 per clock per CU that tools/calib_tcp.hip measures for this pattern
+                rf["l1_lane_access_per_clk"] = round(tr["tcp_lane_accesses_per_launch"] / (kernel_ms_ * 1e-3) / clk_hz / props.multi_processor_count, 3)
+                rf["l1_lane_access_peak"] = 1.0
+            for k_ in ("active_lane_fraction", "valu_issue_utilisation", "waves_per_simd"):
+                if tr.get(k_) is not None:
+                    rf[k_] = tr[k_]
+        return rf
+
+    accel_name = {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel]
+    tree = ("SAH split planes (crt_build_scene_ex CRT_BUILD_SAH: the reference's node format, leaf rule and walk; not the tree the "
+            "reference's builder makes)" if args.builder == "sah" else "the reference's median split (bvh4.h:127-297)")
+    kname = {"bvh4": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "bvh": "k_bvh2<tri_only>", "grid": "k_grid<tri_only>"}[args.accel]
+    tkey = "%s@%s%s" % (args.workload, args.builder, "/shadow" if shadow else "")
     out = {
-        "metric": ("Mrays/s any-hit (shadow rays toward an area light), %s" if shadow else "Mrays/s closest-hit (incoherent), %s")
-        % {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel],
+        "metric": ("Mrays/s any-hit (shadow rays toward an area light), %s" if shadow else "Mrays/s closest-hit (incoherent), %s") % accel_name,
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong_is_value else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), %s, %d %s per GPU per step"
-                               % (args.workload, n_tris, {"bvh4": "QBVH (%s)" % ("SAH split planes" if args.builder == "sah" else "the reference's median split"),
-                                                            "bvh": "binary BVH", "grid": "uniform grid"}[args.accel], n, "shadow rays from the incoherent hit points toward a ceiling light"
-                                  if shadow else "incoherent bounce-1..3 rays"),
-                   "triangles": n_tris, "rays_per_gpu": n, "accel": args.accel.upper(), "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
+        "config": {"workload": "%s: %d-triangle procedural courtyard (San Miguel stand-in), %s, %d %s per %s per step"
+                               % (args.workload, n_tris, accel_name + (" built with " + tree if args.accel == "bvh4" else ""), n,
+                                  "shadow rays from the incoherent hit points toward a ceiling light" if shadow else "incoherent bounce-1..3 rays",
+                                  "job (cut into %d slices)" % world if strong_is_value else "GPU"),
+                   "triangles": n_tris, "rays_per_gpu": rays_per_launch, "accel": args.accel.upper(),
+                   "tree": "sah" if args.builder == "sah" else "reference",
+                   "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
                    if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),
-                   "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "builder": args.builder, "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum,
-                   "scene_build_s": round(build_s, 2)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": {"bvh4": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>",
-                                "bvh": "k_bvh2<tri_only>", "grid": "k_grid<tri_only>"}[args.accel], "kernel_ms": round(avg_kernel_ms, 4), "binning_ms": round(float(np.mean(bin_ms)), 4),
-                     "bytes_per_ray": round(bytes_per_ray, 2), "nodes_per_ray": round(nodes_per_ray, 3),
-                     "tris_per_ray": round(tris_per_ray, 3)},
+                   "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "builder": args.builder,
+                   "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum, "src_hash": shash, "scene_build_s": round(build_s, 2)},
+        "roofline": roofline(kname, avg_kernel_ms, float(np.mean(bin_ms)), nodes_per_ray, tris_per_ray, tkey, checksum, rays_per_launch),
     }
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            key = args.workload + ("@sah" if args.builder == "sah" else "") + ("/shadow" if shadow else "")
-            tr = json.load(open(traffic_file)).get(key) if args.accel == "bvh4" else None
-            if tr and tr.get("rays") == n and args.binning == "on":
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                # measured fabric bytes (PMC, profiles/traffic.json) over the live kernel time: the
-                # caches serve part of the algorithmic bytes, which is how `frac` can pass 1
-                out["roofline"]["traffic_gbs"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9, 1)
-                out["roofline"]["traffic_frac"] = round(tr["hbm_bytes_per_launch"] / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                out["roofline"]["l2_hit_rate"] = tr.get("l2_hit_rate")
-                if tr.get("tcp_lane_accesses_per_launch"):
-                    # the measured limiter: the L1 serves 1.0 lane-divergent access per clock per CU
-                    props = torch.cuda.get_device_properties(device)
-                    clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-                    out["roofline"]["l1_lane_access_per_clk"] = round(
-                        tr["tcp_lane_accesses_per_launch"] / (avg_kernel_ms * 1e-3) / clk_hz / props.multi_processor_count, 3)
-                    out["roofline"]["l1_lane_access_peak"] = 1.0
-        except Exception:
-            pass
+    if other:
+        out[other["scaling"] + "_scaling"] = other
 
     if not shadow and args.accel == "bvh4":
         # secondary metric (BASELINE.json: "any-hit Mrays/s"), outside the timed region: shadow rays from
@@ -353,18 +514,19 @@ def main():
         s_t = torch.empty(n, dtype=torch.float32, device=device)
         s_occ = torch.empty(n, dtype=torch.uint8, device=device)
         s_ms = []
+        barrier()
         for _ in range(4):
             sc.shadow_dev(s_rays.data_ptr(), s_ld.data_ptr(), n, s_t.data_ptr(), s_occ.data_ptr(), stream)
             s_ms.append(sc.last_kernel_ms() + sc.last_binning_ms())
-        s_best = shard.max_over_ranks(float(np.mean(s_ms[1:])), device)
+        s_best = shard.max_over_ranks(float(np.mean(s_ms[1:])), red_device)
         out["any_hit"] = {"metric": "Mrays/s any-hit (shadow rays toward an area light), QBVH",
                           "value": round(n * world / s_best / 1e3, 1), "unit": "Mrays/s", "ms_per_launch": round(s_best, 4),
                           "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
         del s_rays, s_ld, s_t, s_occ
 
     if not shadow and args.accel == "bvh4" and args.builder == "sah" and not args.no_reference_tree:
-        # the same rays through the reference's own median-split QBVH (what `value` was measured on until the SAH builder
-        # existed): rate, traversal statistics, and how many hit records differ between the two trees
+        # the same rays through the tree the reference's own builder makes (integration route (b): the host keeps BVH4_build):
+        # rate, its own roofline block, and how many hit records differ between the two trees
         try:
             built_ref = api.BuiltScene(si, accel, sah=False)
             sc_ref = api.Scene(built_ref, local_rank)
@@ -375,18 +537,25 @@ def main():
             sc_ref.intersect_dev(d_rays.data_ptr(), n, r_hits.data_ptr(), stream)
             rc = sc_ref.counters()
             sc_ref.enable_counters(False)
-            r_ms = []
+            r_ms, r_kms, r_bms = [], [], []
+            barrier()
             for _ in range(4):
                 sc_ref.intersect_dev(d_rays.data_ptr(), n, r_hits.data_ptr(), stream)
-                r_ms.append(sc_ref.last_kernel_ms() + sc_ref.last_binning_ms())
-            r_best = shard.max_over_ranks(float(np.mean(r_ms[1:])), device)
+                r_kms.append(sc_ref.last_kernel_ms())
+                r_bms.append(sc_ref.last_binning_ms())
+                r_ms.append(r_kms[-1] + r_bms[-1])
+            r_best = shard.max_over_ranks(float(np.mean(r_ms[1:])), red_device)
             differ = (r_hits != d_hits).any(dim=1)
             ties = differ & (r_hits[:, 0] == d_hits[:, 0]) & (r_hits[:, 1] != d_hits[:, 1])      # bit-identical t, another object
+            r_chk = int(r_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF
             out["reference_tree"] = {"metric": "Mrays/s closest-hit (incoherent), QBVH built as the reference builds it (median split)",
                                      "value": round(n * world / r_best / 1e3, 1), "unit": "Mrays/s", "ms_per_launch": round(r_best, 4),
-                                     "nodes_per_ray": round(rc["nodes_visited"] / n, 3), "tris_per_ray": round(rc["prims_tested"] / n, 3),
+                                     "hits_checksum": r_chk,
                                      "hit_records_differing_from_sah_tree": int(differ.sum().item()),
-                                     "of_which_exact_t_ties": int(ties.sum().item())}
+                                     "of_which_exact_t_ties": int(ties.sum().item()),
+                                     "roofline": roofline("k_bvh4_closest<tri_only>", float(np.mean(r_kms[1:])), float(np.mean(r_bms[1:])),
+                                                          rc["nodes_visited"] / n, rc["prims_tested"] / n,
+                                                          "%s@reference" % args.workload, r_chk, n)}
             del r_hits
             sc_ref.close()
             built_ref.close()
@@ -399,8 +568,8 @@ def main():
         # (each renders its own sample range of the full frame); the colour buffers are summed over RCCL
         # inside the timed region.
         try:
-            del d_rays, d_hits
-            out["render"] = render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, barrier,
+            del d_rays, d_hits, d_shared
+            out["render"] = render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, red_device, barrier,
                                        n_copies, n_lat, n_lon)
         except Exception as e:  # the headline line must not depend on this leg
             out["render"] = {"error": repr(e)[:300]}
