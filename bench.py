@@ -463,7 +463,14 @@ def main():
                               "gbs_if_nothing_were_cached": round(bpr * n_launch / (kernel_ms_ * 1e-3) / 1e9, 1),
                               "nodes_per_ray": round(nodes, 3), "tris_per_ray": round(tris, 3)}}
         tr = traffic_db.get(key)
-        if tr and tr.get("rays") == n_launch and tr.get("src_hash") == shash and tr.get("hits_checksum") == chk and args.binning == "on":
+        match = None
+        if tr and tr.get("rays") == n_launch and tr.get("src_hash") == shash and args.binning == "on":
+            if tr.get("hits_checksum") == chk:
+                match = "hit-record checksum"
+            elif tr.get("nodes_per_ray") and abs(tr["nodes_per_ray"] / nodes - 1) < 1e-4 and abs(tr["tris_per_ray"] / tris - 1) < 1e-4:
+                match = "nodes and triangles per ray to 1e-4 (ray batch differs in the few rays that leave exact-t ties)"
+        if match:
+            rf["traffic_matched_by"] = match
             t = tr["hbm_bytes_per_launch"]
             gbs = t / (kernel_ms_ * 1e-3) / 1e9
             rf.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": t,

@@ -38,7 +38,9 @@ for d in sorted(os.listdir(src)):
     n = line["config"]["rays_per_gpu"]
     workload = line["config"]["workload"].split(":")[0]
     key = "%s@%s%s" % (workload, builder, "/shadow" if mode == "shadow" else "")
+    alg = line["roofline"]["algorithmic"]
     e = {"rays": n, "hits_checksum": line["config"]["hits_checksum"], "src_hash": line["config"]["src_hash"],
+         "nodes_per_ray": alg["nodes_per_ray"], "tris_per_ray": alg["tris_per_ray"],
          "hbm_bytes_per_launch": int(read_b + write_b), "read_bytes": int(read_b), "write_bytes": int(write_b),
          "read_bytes_from_rdreq": int(vals.get("TCC_EA0_RDREQ_sum", 0) * 128),
          "l2_requests_per_launch": int(vals.get("TCC_REQ_sum", 0)),
@@ -55,10 +57,13 @@ for d in sorted(os.listdir(src)):
     db[key] = e
     shutil.copy(os.path.join(full, "summary.txt"), os.path.join(ROOT, e["source"]))
     print(key, json.dumps(e))
+db = {k: v for k, v in db.items() if k.startswith("_") or (isinstance(v, dict) and "src_hash" in v)}     # entries of older formats go
 db["_how"] = ("rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --no-reference-tree --no-render --steps 5 --warmup 1 --builder B "
               "--mode M` (tools/prof_traffic.sh, one counter group per run), mean per launch of the timed walk-kernel instantiation; "
               "tools/make_traffic.py turns the summaries into these entries. read = 2 x FETCH_SIZE KB (gfx950 tallies 128-B requests at 64 B; "
               "confirmed by tools/calib_fetch.hip, profiles/r01_fetch_size_calibration.txt), write = WRITE_SIZE KB. Infinity-Cache hits are "
-              "included in these counters, so true HBM traffic is at most this. An entry is used by bench.py only when rays, hits_checksum "
-              "and src_hash equal the live run's.")
+              "included in these counters, so true HBM traffic is at most this. An entry is used by bench.py only when rays and src_hash equal the live run's and "
+              "either the hit-record checksum does too or (the reference-tree leg of the default line, whose ray batch was generated through "
+              "the SAH tree and so differs from `--builder reference`'s in the handful of rays that leave exact-t ties) nodes / triangles per "
+              "ray agree to 1e-4.")
 json.dump(db, open(path, "w"), indent=1)
