@@ -110,7 +110,8 @@ METALS = {
 
 class CrtMeshShading(C.Structure):
     _fields_ = [("flat_normal", C.c_void_p), ("vertex_normals", C.c_void_p), ("vertex_tangents", C.c_void_p),
-                ("normal_mat_index", C.c_void_p), ("normal_mats", C.c_void_p), ("num_normal_mats", C.c_int32)]
+                ("normal_mat_index", C.c_void_p), ("normal_mats", C.c_void_p), ("num_normal_mats", C.c_int32),
+                ("vertex_uv", C.c_void_p)]
 
 
 class CrtMesh(C.Structure):
@@ -140,6 +141,11 @@ class CrtRenderStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shadow", C.c_double)]
 
 
+SR_HIT_POINT, SR_NORMAL, SR_DPDU, SR_DPDV, SR_WO, SR_UV, SR_BY_CONVENTION = 1, 2, 4, 8, 16, 32, 256
+SHADE_REC_DTYPE = np.dtype([("hit_point", "<f4", (3,)), ("normal", "<f4", (3,)), ("dpdu", "<f4", (3,)), ("dpdv", "<f4", (3,)),
+                            ("wo", "<f4", (3,)), ("uv", "<f4", (2,)), ("material", "<i4"), ("written", "<u4")])
+assert SHADE_REC_DTYPE.itemsize == 76
+
 # every symbol include/crt_gpu.h declares
 EXPORTS = [
     "crt_scene_file_load", "crt_scene_file_get", "crt_scene_file_free", "crt_env_world_radius",
@@ -148,7 +154,7 @@ EXPORTS = [
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
-    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc",
+    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_fill_shade_rec",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
@@ -204,6 +210,7 @@ def lib():
     L.crt_intersect_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.crt_shadow_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.crt_intersect_batch_dev_noalloc.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    L.crt_fill_shade_rec.argtypes = [C.POINTER(CrtSceneInput), vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.crt_scene_enable_counters.argtypes = [vp, C.c_int]
     L.crt_scene_get_counters.argtypes = [vp, C.POINTER(CrtCounters)]
     L.crt_scene_reset_counters.argtypes = [vp]
@@ -376,15 +383,17 @@ class RenderDesc:
 class MeshShading:
     """crt_mesh_shading: per-triangle shading arrays of FLAT / SMOOTH triangles (any may be None)."""
 
-    def __init__(self, flat_normal=None, vertex_normals=None, vertex_tangents=None, normal_mat_index=None, normal_mats=None):
+    def __init__(self, flat_normal=None, vertex_normals=None, vertex_tangents=None, normal_mat_index=None, normal_mats=None, vertex_uv=None):
         f32 = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)      # noqa: E731
         self.flat_normal, self.vertex_normals, self.vertex_tangents = f32(flat_normal), f32(vertex_normals), f32(vertex_tangents)
         self.normal_mat_index = None if normal_mat_index is None else np.ascontiguousarray(normal_mat_index, np.int32)
         self.normal_mats = f32(normal_mats)
+        self.vertex_uv = f32(vertex_uv)                                       # [T, 6] or None
         c = CrtMeshShading()
         c.flat_normal, c.vertex_normals, c.vertex_tangents = _ptr(self.flat_normal), _ptr(self.vertex_normals), _ptr(self.vertex_tangents)
         c.normal_mat_index, c.normal_mats = _ptr(self.normal_mat_index), _ptr(self.normal_mats)
         c.num_normal_mats = 0 if self.normal_mats is None else len(self.normal_mats.reshape(-1, 9))
+        c.vertex_uv = _ptr(self.vertex_uv)
         self.c = c
 
 
@@ -430,7 +439,8 @@ class SceneFile:
                                                 arr(ms.vertex_normals, nt * 9, np.float32).reshape(-1, 9),
                                                 arr(ms.vertex_tangents, nt * 9, np.float32).reshape(-1, 9),
                                                 arr(ms.normal_mat_index, nt, np.int32),
-                                                arr(ms.normal_mats, ms.num_normal_mats * 9, np.float32).reshape(-1, 9))
+                                                arr(ms.normal_mats, ms.num_normal_mats * 9, np.float32).reshape(-1, 9),
+                                                arr(ms.vertex_uv, nt * 6, np.float32).reshape(-1, 6) if ms.vertex_uv else None)
             self.film = (v.window_width, v.window_height, v.image_width, v.image_height, float(v.fov)) if v.has_film else None
             self.camera = (tuple(v.camera_pos), tuple(v.look_point)) if v.has_camera else None
             self.env_light = (tuple(v.env_color), float(v.env_intensity)) if v.has_env_light else None
@@ -571,6 +581,23 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def fill_shade_rec(scene_input, rays, hits, mesh_shading=None, obj_material=None, conventions=False, out=None, L=None):
+    """crt_fill_shade_rec: the ShadeRec each hit leaves behind (host code).  Returns SHADE_REC_DTYPE[n]; fields the
+    reference's intersector does not write keep the value `out` held (default: NaN, so that they show)."""
+    L = L or lib()
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    hits = np.ascontiguousarray(hits, HIT_DTYPE)
+    if out is None:
+        out = np.zeros(len(rays), SHADE_REC_DTYPE)
+        for f in ("hit_point", "normal", "dpdu", "dpdv", "wo", "uv"):
+            out[f] = np.nan
+    om = None if obj_material is None else np.ascontiguousarray(obj_material, np.int32)
+    cin = scene_input.c_struct()
+    _check(L.crt_fill_shade_rec(C.byref(cin), C.addressof(mesh_shading.c) if mesh_shading is not None else None, _ptr(om),
+                                _ptr(rays), _ptr(hits), len(rays), 1 if conventions else 0, _ptr(out)), "crt_fill_shade_rec")
+    return out
 
 
 def image_state_save(path, color_buffer, num_samples):

@@ -132,7 +132,8 @@ void inverse_transform(float* out16, const float* location, const float* scale, 
 
 struct Loaded {
     std::vector<int32_t> obj_type, obj_ref, obj_material, normal_mat_index;
-    std::vector<float> tri_verts, flat_normal, vertex_normals, vertex_tangents, normal_mats;
+    std::vector<float> tri_verts, flat_normal, vertex_normals, vertex_tangents, normal_mats, vertex_uv;
+    bool any_uv;
     std::vector<crt_shape> shapes;
     std::vector<crt_material> materials;
     std::vector<std::string> names;
@@ -162,9 +163,11 @@ void push_object(Loaded& L, int type, int ref, int mat)
 {
     L.obj_type.push_back(type); L.obj_ref.push_back(ref); L.obj_material.push_back(mat);
 }
-void push_triangle(Loaded& L, int type, const float* v9, int mat, const float* fn, const float* vn9, const float* vt9, int nmi)
+void push_triangle(Loaded& L, int type, const float* v9, int mat, const float* fn, const float* vn9, const float* vt9, int nmi, const float* uv6 = 0)
 {
     static const float z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    L.vertex_uv.insert(L.vertex_uv.end(), uv6 ? uv6 : z9, (uv6 ? uv6 : z9) + 6);
+    if (uv6) L.any_uv = true;
     L.tri_verts.insert(L.tri_verts.end(), v9, v9 + 9);
     L.flat_normal.insert(L.flat_normal.end(), fn ? fn : z9, (fn ? fn : z9) + 3);
     L.vertex_normals.insert(L.vertex_normals.end(), vn9 ? vn9 : z9, (vn9 ? vn9 : z9) + 9);
@@ -222,7 +225,8 @@ void parse_material(Loaded& L, Tokens& tk)
     L.names.push_back(name);
 }
 
-bool parse_normal_type(const std::string& t) { return t == "OPEN" || t == "CONVEX" || t == "CONCAVE"; }
+/* NormalType, shapes/generic.h:13-18; -1: invalid */
+int parse_normal_type(const std::string& t) { return t == "OPEN" ? 0 : t == "CONVEX" ? 1 : t == "CONCAVE" ? 2 : -1; }
 
 int load_mesh(Loaded& L, const std::string& file, const crt_mesh_entry& entry, int mat)
 {
@@ -246,9 +250,16 @@ int load_mesh(Loaded& L, const std::string& file, const crt_mesh_entry& entry, i
         if (rc != CRT_OK) break;
         L.normal_mats.insert(L.normal_mats.end(), nm, nm + 9);
         const int nmi = (int)(L.normal_mats.size() / 9) - 1;
-        for (int k = 0; k < nt; k++)
+        const bool has_uv = sh.num_texcoords == 2 * nv && sh.texcoords;      /* mesh->num_texcoords > 0, triangle.cpp:191 */
+        for (int k = 0; k < nt; k++) {
+            float uv6[6];
+            if (has_uv) for (int c = 0; c < 3; c++) {                        /* texcoords[i*2], [i*2+1] of the triangle's three vertices */
+                const int vi = sh.indices[3 * k + c];
+                uv6[2 * c] = sh.texcoords[2 * (size_t)vi]; uv6[2 * c + 1] = sh.texcoords[2 * (size_t)vi + 1];
+            }
             push_triangle(L, entry.smooth ? CRT_SMOOTH_TRIANGLE : CRT_FLAT_TRIANGLE, &tv[9 * (size_t)k], mat, &fn[3 * (size_t)k],
-                          &vn[9 * (size_t)k], &vt[9 * (size_t)k], nmi);
+                          &vn[9 * (size_t)k], &vt[9 * (size_t)k], nmi, has_uv ? uv6 : 0);
+        }
         L.any_mesh = true;
     }
     crt_obj_free(shapes, ns);
@@ -265,6 +276,7 @@ void parse_object(Loaded& L, Tokens& tk)
     float length = 1.0f, height = 1.0f, width = 1.0f, swept = 1.0f, tube = 0.25f;
     float location[3] = {0, 0, 0}, scale[3] = {1, 1, 1}, orientation[3] = {0, 0, 0};
     bool smooth = false, cast_shadow = true, got_material = false;
+    int normal_type = 0;
     const bool is_box = kind == "BOX";
     while (tk.next(&t)) {
         if (t == "MATERIAL") { got_material = tk.next(&mat_name); break; }      /* always the last field of an entry */
@@ -284,7 +296,7 @@ void parse_object(Loaded& L, Tokens& tk)
         else if (t == "LOCATION") tk.vec3(location);
         else if (t == "SCALE" || t == "SCALING") tk.vec3(scale);
         else if (t == "ORIENTATION" || t == "Orientation") tk.vec3(orientation);
-        else if (t == "NORMAL_TYPE") { tk.next(&t); if (!parse_normal_type(t)) return; }   /* shading only; an invalid one drops the entry (scenefile.h:538-542) */
+        else if (t == "NORMAL_TYPE") { tk.next(&t); normal_type = parse_normal_type(t); if (normal_type < 0) return; }   /* shading only; an invalid one drops the entry (scenefile.h:538-542) */
         else if (t == "SWEPT_RADIUS") tk.number(&swept);
         else if (t == "TUBE_RADIUS") tk.number(&tube);
         else if (t == "FILE_NAME" || t == "FILE") tk.next(&file);
@@ -332,8 +344,8 @@ void parse_object(Loaded& L, Tokens& tk)
         push_object(L, CRT_INSTANCED, push_shape(L, CRT_INSTANCED, 0, 0, inner, 0, 0, inv), mat);
     } else if (kind == "OPENCYLINDER") {                            /* initOpenCylinder, shapes/cylinder.cpp:3-18: half height 1, radius 1 */
         inverse_transform(inv, location, scale, orientation);
-        const float p[3] = { 1.0f, 1.0f, phi };
-        const int inner = push_shape(L, CRT_GENERICOPENCYLINDER, p, 3);
+        const float p[4] = { 1.0f, 1.0f, phi, (float)normal_type };
+        const int inner = push_shape(L, CRT_GENERICOPENCYLINDER, p, 4);
         push_object(L, CRT_INSTANCED, push_shape(L, CRT_INSTANCED, 0, 0, inner, 0, 0, inv), mat);
     } else if (kind == "SOLIDCYLINDER") {                           /* initSolidCylinder(inv, 1, 1, PI), shapes/cylinder.cpp:29-75 */
         inverse_transform(inv, location, scale, orientation);
@@ -393,6 +405,7 @@ int crt_scene_file_load(const char* path, crt_scene_file** out)
     Loaded& L = sf->L;
     memset(&L.view, 0, sizeof L.view);
     L.any_mesh = false;
+    L.any_uv = false;
     {
         const std::string p(path);
         const size_t slash = p.find_last_of('/');
@@ -437,6 +450,7 @@ int crt_scene_file_load(const char* path, crt_scene_file** out)
     V.mesh_shading.normal_mat_index = L.normal_mat_index.data();
     V.mesh_shading.normal_mats = L.normal_mats.data();
     V.mesh_shading.num_normal_mats = (int32_t)(L.normal_mats.size() / 9);
+    V.mesh_shading.vertex_uv = L.any_uv ? L.vertex_uv.data() : 0;
     *out = sf;
     return CRT_OK;
 }

@@ -79,13 +79,25 @@ typedef struct crt_ray { float o[3]; float d[3]; } crt_ray;
  *           (triangle.cpp:44-45); 0 for other shapes and on miss. */
 typedef struct crt_hit { float t; int32_t obj; int32_t part; float beta; float gamma; } crt_hit;
 
+/* ---- hit record -> ShadeRec, host side ------------------------------------------------
+ * ShadeRec (util/shaderec.h:7-19) without its by-value Material / BSDF copies (an index instead).  `written`:
+ * which fields the reference's intersector writes for the shape that was hit -- the others are left as passed in,
+ * as the reference leaves them holding whatever the record held before. */
+enum { CRT_SR_HIT_POINT = 1, CRT_SR_NORMAL = 2, CRT_SR_DPDU = 4, CRT_SR_DPDV = 8, CRT_SR_WO = 16, CRT_SR_UV = 32,
+       CRT_SR_BY_CONVENTION = 256 };   /* some field was filled by this library's convention, not by reference code (see below) */
+typedef struct crt_shade_rec {
+    float    hit_point[3], normal[3], dpdu[3], dpdv[3], wo[3], uv[2];
+    int32_t  material;                 /* obj_material[hit.obj] (getObjectMatPtr's material, as an index), -1 when no map is given */
+    uint32_t written;                  /* CRT_SR_* ; 0 for a miss */
+} crt_shade_rec;
+
 /* ---- analytic shapes --------------------------------------------------- */
 /* One non-triangle shape.  p[] holds the geometric fields of the reference struct:
  *   SPHERE   (sphere.h:10-17)   p = center[3], radius, min_theta, max_theta, phi
  *   PLANE    (plane.h:8-14)     p = point[3], normal[3]
  *   RECTANGLE(rect.h:9-16)      p = point[3], width[3], height[3], normal[3]
  *   AABOX    (generic.h AABox)  p = min[3], max[3], shadow (0/1)
- *   GENERICOPENCYLINDER         p = half_height, radius, phi
+ *   GENERICOPENCYLINDER         p = half_height, radius, phi, normal_type (0 OPEN, 1 CONVEX, 2 CONCAVE: generic.h:13-18; shading only)
  *   DISK     (disk.h:9-16)      p = center[3], normal[3], radius
  *   GENERICTORUS                p = swept_radius, tube_radius, phi
  *   COMPOUND (instanced.h:7-13) p = aabb.min[3], aabb.max[3]; parts = shapes[first_part .. first_part+num_parts)
@@ -318,6 +330,8 @@ typedef struct crt_mesh_shading {
     const int32_t* normal_mat_index;
     const float*   normal_mats;
     int32_t        num_normal_mats;
+    const float*   vertex_uv;            /* [tri][6]: mesh->texcoords of the three vertices (interpTexcoord, triangle.cpp:170-183), or NULL
+                                            (a mesh without texcoords: the reference interpolates nothing, triangle.cpp:191-194) */
 } crt_mesh_shading;
 
 typedef struct crt_render_desc {
@@ -367,6 +381,24 @@ int  crt_renderer_reset(crt_renderer* r, uint32_t next_sample);
  * crt_renderer_render calls have completed): for reducing the buffers of several GPUs over RCCL. */
 int  crt_renderer_read_dev(crt_renderer* r, float* d_color_buffer, void* stream);
 int  crt_renderer_get_stats(crt_renderer* r, crt_render_stats* out);
+
+/* ---- hit -> ShadeRec, host side (row a-13; the records are crt_shade_rec, above) ---------------------------- */
+/* The ShadeRec each of n hits leaves behind: what `intersectTest(&sr, so, ray)` wrote into `sr` through the intersector
+ * of the object that was hit -- rayIntersectTriangle / FlatTriangle / SmoothTriangle (triangle.cpp:154-258),
+ * fillShadeRecSphere (sphere.cpp:3-31), rayIntersectPlane (plane.cpp:10-16), rayIntersectRect (rect.cpp:34-46),
+ * rayIntersectDisk (disk.cpp:13-24), rayIntersectAABox / fillShadeRecGenericOpenCylinder / rayIntersectGenericTorus
+ * (generic.cpp:3-32,:199-220,:384-401), rayIntersectInstanced (instanced.cpp:92-101: normal through the transposed inverse
+ * transform, not renormalised), rayIntersectCompound (the winning part's record) -- rebuilt on the host from
+ * {t, obj, part, beta, gamma}.  `in` = the insertion-order arrays the scene was built from (hit ids index them),
+ * `mesh_shading` / `obj_material` may be NULL.  Plain host code, no GPU involved.
+ * conventions = 0: exactly the reference's writes.  conventions != 0: additionally the fields pathTrace reads but the
+ * reference never writes get this library's documented values (flag CRT_SR_BY_CONVENTION): dpdu of TRIANGLE /
+ * FLAT_TRIANGLE = normalize(v1 - v0); dpdu of plane, disk, box, cylinder, torus = normalize(JITTERED_UP x normal); the
+ * normal of a disk hit from behind = the disk's normal (disk.cpp:16-19 overwrites wo instead); a torus hit outside
+ * the phi window (generic.cpp:207-220 returns t and writes nothing) filled as if inside.  These are what
+ * crt_renderer_* shades with. */
+int  crt_fill_shade_rec(const crt_scene_input* in, const crt_mesh_shading* mesh_shading, const int32_t* obj_material,
+                        const crt_ray* rays, const crt_hit* hits, size_t n, int conventions, crt_shade_rec* out);
 
 /* ---- mesh baking (part of SURVEY 8f N2), host side ----------------------------------- */
 /* Mesh (mesh.h:11-22): the arrays generateMeshTriangles reads.  normals / tangents may be NULL. */

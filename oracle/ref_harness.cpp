@@ -126,7 +126,7 @@ static void* make_shape(const crt_scene_input* in, int si, int* type_out, Materi
     }
     case CRT_GENERICOPENCYLINDER: {
         GenericOpenCylinder* s = (GenericOpenCylinder*)calloc(1, sizeof(GenericOpenCylinder));
-        s->half_height = p[0]; s->radius = p[1]; s->phi = p[2]; s->normal_type = OPEN; s->mat = mat;
+        s->half_height = p[0]; s->radius = p[1]; s->phi = p[2]; s->normal_type = (NormalType)(int)p[3]; s->mat = mat;
         return s;
     }
     case CRT_DISK: {
@@ -319,6 +319,14 @@ static void fill_details(const ref_scene* s, void* ptr, const Ray ray, crt_hit* 
                 if (t < min_t) { min_t = t; out->part = i; }
             }
         }
+    } else if (obj.type == COMPOUND) {                             /* a compound that is not inside an instance */
+        CompoundObject* co = (CompoundObject*)obj.ptr;
+        float min_t = TMAX;
+        for (int i = 0; i < co->num_obj; i++) {
+            ShadeRec tmp;
+            float t = rayIntersectObject(&tmp, co->objects[i], ray);
+            if (t < min_t) { min_t = t; out->part = i; }
+        }
     }
 }
 
@@ -495,6 +503,20 @@ REF_API float ref_shade_rec(const ref_scene* s, int final_index, const crt_ray* 
     vec3_assign(sr.normal, dpdu_marker, dpdu_marker, dpdu_marker);
     float t = rayIntersectObject(&sr, s->objects[final_index], r);
     memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+    return t;
+}
+/* Every geometric field of the record: out = hit_point, normal, dpdu, dpdv, wo (3 each), uv (2) = 17 floats, all pre-set to
+ * `marker` so that what the intersector of that shape kind never writes shows (row a-13: crt_fill_shade_rec's `written`). */
+REF_API float ref_shade_rec_full(const ref_scene* s, int final_index, const crt_ray* ray, float* out, float marker)
+{
+    Ray r; to_ray(&r, ray);
+    ShadeRec sr;
+    vec3_assign(sr.hit_point, marker, marker, marker); vec3_assign(sr.normal, marker, marker, marker);
+    vec3_assign(sr.dpdu, marker, marker, marker); vec3_assign(sr.dpdv, marker, marker, marker);
+    vec3_assign(sr.wo, marker, marker, marker); vec2_assign(sr.uv, marker, marker);
+    float t = rayIntersectObject(&sr, s->objects[final_index], r);
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.dpdu, 12); memcpy(out + 9, sr.dpdv, 12);
+    memcpy(out + 12, sr.wo, 12); memcpy(out + 15, sr.uv, 8);
     return t;
 }
 REF_API void ref_map_sample_to_disk(const float* in, float* out) { vec2 i = { in[0], in[1] }; vec2 o; mapSampleToDisk(o, i); out[0] = o[0]; out[1] = o[1]; }
@@ -684,6 +706,47 @@ REF_API float ref_mesh_triangle_shade_rec(int smooth, const float* v, const floa
         t = rayIntersectFlatTriangle(&sr, &tri, r);
     }
     memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+    vec3 v0, v1, v2; memcpy(v0, v, 12); memcpy(v1, v + 3, 12); memcpy(v2, v + 6, 12);
+    calcTriangleIntersect(bg, bg + 1, v0, v1, v2, r);
+    return t;
+}
+/* The same with texture coordinates (uv6 = the three vertices' texcoords, NULL: a mesh without any) and every field out:
+ * out = hit_point, normal, dpdu, dpdv, wo, uv (17 floats), pre-set to `marker`. */
+REF_API float ref_mesh_triangle_shade_rec_full(int smooth, const float* v, const float* vn, const float* vt, const float* uv6,
+                                               const float* flat_normal, const float* normal_mat, const crt_ray* ray, float* out,
+                                               float* bg, float marker)
+{
+    Ray r; to_ray(&r, ray);
+    Mesh mesh; memset(&mesh, 0, sizeof mesh);
+    float normals[9], texcoords[6] = {0, 0, 0, 0, 0, 0};
+    vec3 tangents[3];
+    memcpy(normals, vn, sizeof normals); memcpy(tangents, vt, sizeof tangents);
+    if (uv6) memcpy(texcoords, uv6, sizeof texcoords);
+    mesh.normals = normals; mesh.tangents = tangents; mesh.texcoords = texcoords; mesh.num_texcoords = uv6 ? 6 : 0;
+    mat3 nm; memcpy(nm, normal_mat, sizeof nm);
+    ShadeRec sr;
+    vec3_assign(sr.hit_point, marker, marker, marker); vec3_assign(sr.normal, marker, marker, marker);
+    vec3_assign(sr.dpdu, marker, marker, marker); vec3_assign(sr.dpdv, marker, marker, marker);
+    vec3_assign(sr.wo, marker, marker, marker);
+    vec2_assign(sr.uv, 0.25f, 0.75f);                              /* inside [0, 1]: FlatTriangle's wrap loops (triangle.cpp:195-198) leave it alone */
+    Material dummy; memset(&dummy, 0, sizeof dummy);
+    float t;
+    if (smooth) {
+        SmoothTriangle tri; memset(&tri, 0, sizeof tri);
+        tri.i0 = 0; tri.i1 = 1; tri.i2 = 2;
+        memcpy(tri.v0, v, 12); memcpy(tri.v1, v + 3, 12); memcpy(tri.v2, v + 6, 12);
+        tri.normal_mat = &nm; tri.mesh_ptr = &mesh; tri.mat = &dummy;
+        t = rayIntersectSmoothTriangle(&sr, &tri, r);
+    } else {
+        FlatTriangle tri; memset(&tri, 0, sizeof tri);
+        tri.i0 = 0; tri.i1 = 1; tri.i2 = 2;
+        memcpy(tri.v0, v, 12); memcpy(tri.v1, v + 3, 12); memcpy(tri.v2, v + 6, 12);
+        memcpy(tri.normal, flat_normal, 12);
+        tri.mesh_ptr = &mesh; tri.mat = &dummy;
+        t = rayIntersectFlatTriangle(&sr, &tri, r);
+    }
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.dpdu, 12); memcpy(out + 9, sr.dpdv, 12);
+    memcpy(out + 12, sr.wo, 12); memcpy(out + 15, sr.uv, 8);
     vec3 v0, v1, v2; memcpy(v0, v, 12); memcpy(v1, v + 3, 12); memcpy(v2, v + 6, 12);
     calcTriangleIntersect(bg, bg + 1, v0, v1, v2, r);
     return t;

@@ -135,6 +135,10 @@ def ref():
         L.ref_primary_rays.restype = None
         L.ref_shade_rec.argtypes = [vp, C.c_int, vp, vp, C.c_float]
         L.ref_shade_rec.restype = C.c_float
+        L.ref_shade_rec_full.argtypes = [vp, C.c_int, vp, vp, C.c_float]
+        L.ref_shade_rec_full.restype = C.c_float
+        L.ref_mesh_triangle_shade_rec_full.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float]
+        L.ref_mesh_triangle_shade_rec_full.restype = C.c_float
         for name in ("ref_map_sample_to_disk", "ref_map_sample_to_hemisphere"):
             getattr(L, name).argtypes = [vp, vp]
             getattr(L, name).restype = None

@@ -1,0 +1,204 @@
+"""crt_fill_shade_rec (hit record -> ShadeRec on the host) against the reference's own
+intersectors compiled from /root/reference into oracle/_ref: for every hit, rayIntersectObject(&sr, objects[k], ray)
+is run on a record pre-filled with a marker, so the test sees both WHAT the reference writes and WHICH fields it
+writes for that shape kind.  The product must give the same bits in the written fields, say `written` for exactly
+those fields, and leave the others alone.  All 12 object types: sphere (whole and partial), plane, rectangle,
+triangle, disk, instanced box / torus / open cylinder (OPEN, CONVEX, CONCAVE) / solid cylinder (a 3-part compound),
+a bare compound, FLAT and SMOOTH mesh triangles with and without texture coordinates.
+
+Also here (no reference needed): the conventions switch and the argument checks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from craytracer_amd import api, scenes
+import oraclelib as ol
+
+MARK = np.float32(-123.25)
+FIELDS = (("hit_point", 0, 3, api.SR_HIT_POINT), ("normal", 3, 3, api.SR_NORMAL), ("dpdu", 6, 3, api.SR_DPDU),
+          ("dpdv", 9, 3, api.SR_DPDV), ("wo", 12, 3, api.SR_WO), ("uv", 15, 2, api.SR_UV))
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def shapes_scene(rotated):
+    """scenes.analytic_scene plus what it lacks: a partial sphere, CONVEX and CONCAVE cylinders, a bare compound."""
+    sl = scenes.ShapeList()
+    sl.sphere((-2.0, 1.0, 0.0), 1.0)
+    sl.sphere((2.5, 2.5, 2.5), 0.8, 0.4, 2.6, 2.2)                               # min_theta, max_theta, phi
+    sl.plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0))
+    sl.rectangle((1.0, -1.0, -3.0), (4.0, 0.0, 0.0), (0.0, 4.0, -4.0))
+    sl.triangle([3.0, 0.0, 2.0, 5.0, 0.0, 2.0, 4.0, 2.0, 2.0])
+    sl.disk((3.0, 3.0, 0.0), scenes._normalize32((1.0, 0.0, 1.0)), 1.0)
+    e = (20.0, 35.0, 10.0) if rotated else (0.0, 0.0, 0.0)
+    s = (1.5, 0.75, 1.25) if rotated else (1.0, 1.0, 1.0)
+    sl.box(scenes.inv_transform((-4.0, 0.5, -2.0), s, e), 1.0, 2.0, 1.5)
+    sl.torus(scenes.inv_transform((0.0, 0.5, 3.0), s, e), 2.0, 0.3)
+    for k, loc in enumerate(((-1.0, 0.0, -4.0), (-3.0, 2.0, 3.0), (4.0, 3.0, -3.0))):
+        sl.open_cylinder(scenes.inv_transform(loc, s, e))
+        sl.shapes[-2]["p"][3] = float(k)                                          # NormalType OPEN / CONVEX / CONCAVE of the inner cylinder
+    sl.solid_cylinder(scenes.inv_transform((5.0, 1.0, -1.0), s, e), 0.5, 1.0)
+    # a compound that is not inside an instance: two disks and a tube, in world space
+    first = sl._shape(api.DISK, [0.0, 3.6, 0.0, 0.0, 1.0, 0.0, 0.7])
+    sl._shape(api.DISK, [0.0, 2.4, 0.0, 0.0, -1.0, 0.0, 0.7])
+    sl._shape(api.SPHERE, [0.0, 3.0, 0.0, 0.5, 0.0, 3.14159, 3.14159])
+    sl._obj(api.COMPOUND, sl._shape(api.COMPOUND, [-0.7, 2.4, -0.7, 0.7, 3.6, 0.7], first_part=first, num_parts=3))
+    return sl.to_input()
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("rotated", [False, True])
+def test_every_shape_kind_against_the_reference(rotated):
+    si = shapes_scene(rotated)
+    rs = ol.RefScene(si, api.ACCEL_NONE)
+    order, _ = rs.order()
+    final_of = {int(i): k for k, i in enumerate(order)}
+    rays = scenes.random_rays(60000, np.float32([-6, -1.5, -6]), np.float32([6, 5, 6]), seed=17 + rotated)
+    hits = rs.intersect(rays)
+    got = api.fill_shade_rec(si, rays, hits)
+    R = ol.ref()
+    seen = {}
+    inner_kind = lambda obj: int(si.shapes[si.shapes[si.obj_ref[obj]]["inner"]]["type"]) if si.obj_type[obj] == api.INSTANCED else -1   # noqa: E731
+    for i in np.nonzero(hits["obj"] >= 0)[0]:
+        obj = int(hits["obj"][i])
+        want = np.zeros(17, np.float32)
+        t = R.ref_shade_rec_full(rs.h, final_of[obj], _p(rays[i]), _p(want), MARK)
+        assert np.float32(t) == hits["t"][i]
+        g = got[i]
+        kind = (int(si.obj_type[obj]), inner_kind(obj), int(hits["part"][i]))
+        for name, off, n, bit in FIELDS:
+            w = want[off:off + n]
+            ref_wrote = bool((w != MARK).any())
+            if bit & int(g["written"]):
+                assert ol.same_bits(g[name], w), (kind, name, g[name], w)
+            else:
+                # not written by the product: the reference must not have written it either
+                if name == "normal" and si.obj_type[obj] == api.INSTANCED:
+                    continue                                       # the marker pushed through the transposed matrix: not a write of the shape
+                if api.COMPOUND in kind[:2]:
+                    continue                                       # rayIntersectCompound copies an uninitialised local ShadeRec over the
+                                                                   # caller's (instanced.cpp:163,:209-213): unwritten fields hold stack garbage
+                assert not ref_wrote, (kind, name, w)
+                assert np.isnan(g[name]).all(), (kind, name)       # left as passed in
+        seen[kind] = seen.get(kind, 0) + 1
+    kinds = set(seen)
+    T = api
+    for need in ((T.SPHERE, -1, 0), (T.PLANE, -1, 0), (T.RECTANGLE, -1, 0), (T.TRIANGLE, -1, 0), (T.DISK, -1, 0), (T.INSTANCED, T.AABOX, 0),
+                 (T.INSTANCED, T.GENERICTORUS, 0), (T.INSTANCED, T.GENERICOPENCYLINDER, 0), (T.INSTANCED, T.COMPOUND, 0),
+                 (T.INSTANCED, T.COMPOUND, 1), (T.INSTANCED, T.COMPOUND, 2), (T.COMPOUND, -1, 0), (T.COMPOUND, -1, 1), (T.COMPOUND, -1, 2)):
+        assert need in kinds and seen[need] >= 5, (need, seen)
+    # the disk's back side: wo overwritten with -normal, normal untouched (disk.cpp:16-19)
+    disk = np.nonzero((hits["obj"] >= 0) & (si.obj_type[np.maximum(hits["obj"], 0)] == api.DISK))[0]
+    back = [i for i in disk if not (int(got[i]["written"]) & api.SR_NORMAL)]
+    assert len(back) > 3 and len(back) < len(disk)
+
+
+@pytest.mark.ref
+def test_written_mask_per_kind():
+    """What each intersector writes, as found by the marker (documented in include/crt_gpu.h)."""
+    si = shapes_scene(True)
+    rs = ol.RefScene(si, api.ACCEL_NONE)
+    rays = scenes.random_rays(30000, np.float32([-6, -1.5, -6]), np.float32([6, 5, 6]), seed=5)
+    hits = rs.intersect(rays)
+    got = api.fill_shade_rec(si, rays, hits)
+    A = api
+    full = A.SR_HIT_POINT | A.SR_NORMAL | A.SR_WO
+    expect = {A.SPHERE: {full | A.SR_UV | A.SR_DPDU | A.SR_DPDV}, A.PLANE: {full}, A.RECTANGLE: {full | A.SR_UV | A.SR_DPDU | A.SR_DPDV},
+              A.TRIANGLE: {full}, A.DISK: {full, A.SR_HIT_POINT | A.SR_WO}}
+    for i in np.nonzero(hits["obj"] >= 0)[0]:
+        typ = int(si.obj_type[hits["obj"][i]])
+        if typ in expect:
+            assert int(got[i]["written"]) in expect[typ], (typ, int(got[i]["written"]))
+    assert (got["written"][hits["obj"] < 0] == 0).all()
+
+
+@pytest.mark.ref
+def test_mesh_triangles_with_and_without_texcoords():
+    R = ol.ref()
+    rng = np.random.default_rng(9)
+    n_ok = 0
+    for case in range(400):
+        smooth = case % 2
+        with_uv = (case // 2) % 2
+        v = (rng.random(9, dtype=np.float32) * 2 - 1).astype(np.float32)
+        vn = rng.standard_normal(9).astype(np.float32)
+        vt = rng.standard_normal(9).astype(np.float32)
+        uv6 = (rng.random(6, dtype=np.float32) * 6 - 3).astype(np.float32)        # outside [0, 1]: the wrap loops run
+        fn = rng.standard_normal(3).astype(np.float32)
+        fn /= np.linalg.norm(fn)
+        nm = (np.eye(3) + 0.3 * rng.standard_normal((3, 3))).astype(np.float32).reshape(9)
+        c = v.reshape(3, 3).mean(0)
+        o = (c + rng.standard_normal(3) * 2).astype(np.float32)
+        tgt = (v.reshape(3, 3) * rng.dirichlet([1, 1, 1])[:, None]).sum(0)
+        d = (tgt - o).astype(np.float32)
+        d /= np.linalg.norm(d)
+        ray = np.concatenate([o, d]).astype(np.float32)
+        want, bg = np.zeros(17, np.float32), np.zeros(2, np.float32)
+        t = R.ref_mesh_triangle_shade_rec_full(smooth, _p(v), _p(vn), _p(vt), _p(uv6) if with_uv or smooth else None, _p(fn), _p(nm), _p(ray),
+                                               _p(want), _p(bg), MARK)
+        if not np.float32(t) < api.TMAX:
+            continue
+        si = api.SceneInput(v.reshape(1, 9), None, np.array([api.SMOOTH_TRIANGLE if smooth else api.FLAT_TRIANGLE], np.int32), np.array([0], np.int32))
+        ms = api.MeshShading(fn.reshape(1, 3), vn.reshape(1, 9), vt.reshape(1, 9), np.array([0], np.int32), nm.reshape(1, 9),
+                             uv6.reshape(1, 6) if with_uv or smooth else None)
+        hit = np.zeros(1, api.HIT_DTYPE)
+        hit["t"], hit["obj"], hit["beta"], hit["gamma"] = np.float32(t), 0, bg[0], bg[1]
+        g = api.fill_shade_rec(si, ray.reshape(1, 6), hit, mesh_shading=ms)[0]
+        for name, off, n, bit in FIELDS:
+            w = want[off:off + n]
+            if bit & int(g["written"]):
+                assert ol.same_bits(g[name], w), (smooth, with_uv, name, g[name], w)
+            elif name == "uv":
+                assert (w == np.float32([0.25, 0.75])).all()       # the harness's initial value: nothing interpolated
+            else:
+                assert (w == MARK).all(), (smooth, with_uv, name, w)
+        assert bool(int(g["written"]) & api.SR_UV) == bool(with_uv or smooth)
+        n_ok += 1
+    assert n_ok > 300
+
+
+def test_conventions_fill_what_the_reference_leaves_unset():
+    si = shapes_scene(True)
+    o = ol.OracleScene(si, api.ACCEL_NONE)
+    rays = scenes.random_rays(30000, np.float32([-6, -1.5, -6]), np.float32([6, 5, 6]), seed=23)
+    hits = o.intersect(rays)
+    o.close()
+    plain = api.fill_shade_rec(si, rays, hits, conventions=False)
+    conv = api.fill_shade_rec(si, rays, hits, conventions=True, obj_material=np.arange(si.num_obj, dtype=np.int32)[::-1].copy())
+    hit = hits["obj"] >= 0
+    # with conventions every hit has a normal, a unit dpdu perpendicular enough to build a frame, hit point and wo
+    assert not np.isnan(conv["normal"][hit]).any() and not np.isnan(conv["dpdu"][hit]).any()
+    assert not np.isnan(conv["hit_point"][hit]).any() and not np.isnan(conv["wo"][hit]).any()
+    ln = np.linalg.norm(conv["dpdu"][hit], axis=1)
+    assert np.allclose(ln, 1.0, atol=1e-5)
+    # what the reference writes is untouched by the switch
+    for name, _, _, bit in FIELDS:
+        m = hit & ((plain["written"] & bit) != 0)
+        assert ol.same_bits(plain[name][m], conv[name][m]), name
+    # TRIANGLE: dpdu = normalize(v1 - v0), flagged
+    tri = hit & (si.obj_type[np.maximum(hits["obj"], 0)] == api.TRIANGLE)
+    assert tri.any() and ((conv["written"][tri] & api.SR_BY_CONVENTION) != 0).all() and np.isnan(plain["dpdu"][tri]).all()
+    # the material index follows the map
+    assert (conv["material"][hit] == (si.num_obj - 1 - hits["obj"][hit])).all() and (conv["material"][~hit] == -1).all()
+    assert (plain["material"] == -1).all()
+
+
+def test_argument_checks():
+    L = api.lib()
+    si = scenes.analytic_scene()
+    cin = si.c_struct()
+    rays = np.zeros((2, 6), np.float32)
+    hits = np.zeros(2, api.HIT_DTYPE)
+    hits["obj"] = [-1, 10 ** 6]                                    # a miss and an id outside the scene: nothing written, no crash
+    out = api.fill_shade_rec(si, rays, hits)
+    assert (out["written"] == 0).all()
+    assert L.crt_fill_shade_rec(None, None, None, _p(rays), _p(hits), 2, 0, _p(out)) == -1
+    assert L.crt_fill_shade_rec(C.byref(cin), None, None, None, _p(hits), 2, 0, _p(out)) == -1
+    assert L.crt_fill_shade_rec(C.byref(cin), None, None, None, None, 0, 0, None) == 0
+    bad = api.SceneInput(si.tri_verts, si.shapes, si.obj_type, si.obj_ref.copy())
+    bad.obj_ref[0] = 999
+    cb = bad.c_struct()
+    assert L.crt_fill_shade_rec(C.byref(cb), None, None, _p(rays), _p(hits), 2, 0, _p(out)) == -1
