@@ -25,6 +25,7 @@
 #include "../../include/crt_gpu.h"
 #include "crt_camera.h"
 #include "crt_libm.h"
+#include "crt_shaderec.h"
 
 namespace {
 
@@ -377,7 +378,7 @@ enum { DIM_IMAGE = 0, DIM_LENS = 2, DIM_BOUNCE0 = 4, DIMS_PER_BOUNCE = 8,
 struct ShadeObj {
     int32_t type, mat;
     float p[14];      /* TRIANGLE / FLAT: normal[3] tangent[3] | RECTANGLE: normal[3] dpdu[3] point[3] | SPHERE: center[3] radius |
-                         SMOOTH: triangle index, normal_mat index (as int bits) */
+                         SMOOTH: triangle index, normal_mat index (as int bits) | every other kind: index into shapes[] (as int bits) */
 };
 enum { LIGHT_ENV = 0, LIGHT_AREA = 1 };
 struct LightRec {
@@ -389,6 +390,7 @@ struct LightRec {
 struct RenderDev {
     const ShadeObj* objs; const crt_material* mats; const LightRec* lights;
     const float* vnormals; const float* vtangents; const float* normal_mats;      /* SMOOTH_TRIANGLE: crt_mesh_shading arrays */
+    const crt_shape* shapes; int32_t num_shapes;                                  /* plane / disk / box / cylinder / torus / instanced / compound hits */
     int32_t num_lights, has_env, max_depth;
     float env_color[3], env_intensity, env_world_radius;
     uint32_t seed_lo, seed_hi, npix;
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             const V3 ro = v3p(ray.o), rdir = v3p(ray.d);
             const V3 hp = add(ro, scale(rdir, hit.t));            /* getPointOnRay, util/ray.cpp:4-9 */
             const V3 wo = neg(rdir);
+            V3 wo_sr = wo;                                        /* ShadeRec.wo: what estimateDirect hands BSDF_f (trace.h:328); differs from -d only behind a disk */
             V3 normal, dpdu;
             if (so.type == CRT_TRIANGLE) {                        /* triangle.cpp:159-166 */
                 normal = v3p(so.p); dpdu = v3p(so.p + 3);
@@ -513,6 +516,13 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 normal = dot(disp, rn) < 0.0f ? neg(rn) : rn;
                 dpdu = v3p(so.p + 3);
                 if (dot(wo, normal) < 0.0f) { normal = neg(normal); dpdu = neg(dpdu); }
+            } else if (so.type != CRT_SPHERE) {                   /* plane, disk, box, cylinder, torus, instanced, compound: crt_shaderec.h */
+                crt_shade_rec sr;
+                sr.written = 0;
+                sr.normal[0] = sr.normal[1] = sr.normal[2] = 0.0f; sr.dpdu[0] = sr.dpdu[1] = sr.dpdu[2] = 0.0f;
+                sr.wo[0] = wo.x; sr.wo[1] = wo.y; sr.wo[2] = wo.z;
+                sr_fill_shape_object(rd.shapes, rd.num_shapes, __float_as_int(so.p[0]), &ray, &hit, 1, &sr);
+                normal = v3p(sr.normal); dpdu = v3p(sr.dpdu); wo_sr = v3p(sr.wo);
             } else {                                              /* SPHERE, sphere.cpp:7-10,:25-29 */
                 const V3 c = v3p(so.p);
                 normal = normalize(sub(hp, c));
@@ -584,8 +594,8 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 const V3 Li = scale(v3p(lt.color), lt.intensity);
                 const V3 s2h = sub(sp, hp);
                 if (!(dot(s2h, sn) > 0.0f || dot(s2h, normal) < 0.0f) && lpdf > 0.0f && !is_black(Li)) {
-                    V3 f = mat.type == CRT_MAT_PLASTIC ? fb_diffuse_f(wi, wo, mat)                /* the DIFFUSE lobe of the two, on the WORLD vectors too */
-                         : oren ? scale(cd, oren_nayar_scale(wi, wo, mat.ior_in, mat.ior_out))    /* OrenNayar_f on the WORLD vectors */
+                    V3 f = mat.type == CRT_MAT_PLASTIC ? fb_diffuse_f(wi, wo_sr, mat)             /* the DIFFUSE lobe of the two, on the WORLD vectors too */
+                         : oren ? scale(cd, oren_nayar_scale(wi, wo_sr, mat.ior_in, mat.ior_out)) /* OrenNayar_f on the WORLD vectors */
                                 : scale(cd, (float)RD_INV_PI);    /* Lambertian_f, reflection.cpp:159-163 */
                     f = scale(f, fabsf(dot(normal, wi)));
                     if (!is_black(f)) {
@@ -783,7 +793,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     std::vector<ShadeObj> objs((size_t)in->num_obj);
     std::vector<LightRec> lights;
     const crt_mesh_shading* ms = d->mesh_shading;
-    bool any_smooth = false;
+    bool any_smooth = false, any_generic = false;
     if (d->has_env_light && d->env_intensity > 0.0f) {            /* the scene file's ENV_LIGHT precedes the objects: light 0; with intensity <= 0 it
                                                                      is seen (black) but is no light, buildscene.h:525-533 */
         LightRec l; memset(&l, 0, sizeof l);
@@ -831,8 +841,9 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
                 memcpy(so.p + 6, sp, 12);                         /* point */
             } else if (type == CRT_SPHERE) {
                 memcpy(so.p, sp, 16);                             /* center, radius */
-            } else if (mt.type != CRT_MAT_EMISSIVE) {
-                return CRT_E_UNSUPPORTED;                         /* disk.cpp:15-22 leaves the normal of a back-side hit unset */
+            } else {                                              /* DISK: shaded through crt_shaderec.h (its back side by convention) */
+                memcpy(so.p, &ref, 4);
+                any_generic = true;
             }
             if (mt.type == CRT_MAT_EMISSIVE) {                    /* initAreaLights, buildscene.h:567-608 */
                 LightRec l; memset(&l, 0, sizeof l);
@@ -846,6 +857,13 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
                 l.power = (l.color[0] * l.color[1] * l.color[2]) / 3.0f * l.intensity * area;   /* buildscene.h:914-915 (a product, as written there) */
                 lights.push_back(l);
             }
+        } else if (type == CRT_PLANE || type == CRT_AABOX || type == CRT_GENERICOPENCYLINDER || type == CRT_GENERICTORUS ||
+                   type == CRT_INSTANCED || type == CRT_COMPOUND) {
+            /* the shapes whose intersectors leave dpdu (and more) unset: shaded with the conventions of crt_fill_shade_rec
+             * (DESIGN.md "a-13"); nesting as crt_scene_create allows it: instanced { simple | compound { simple } } */
+            if (ref < 0 || ref >= in->num_shapes || !in->shapes || in->shapes[ref].type != type) return CRT_E_INVALID;
+            memcpy(so.p, &ref, 4);
+            any_generic = true;
         } else {
             return CRT_E_UNSUPPORTED;
         }
@@ -878,7 +896,24 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     RenderDev& rd = r->rd;
     ShadeObj* d_objs = 0; crt_material* d_mats = 0; LightRec* d_lights = 0;
     float* d_vn = 0; float* d_vt = 0; float* d_nm = 0;
+    crt_shape* d_shapes = 0;
+    if (any_generic) {                                            /* every index sr_fill_shape_object follows, checked before the kernel sees it */
+        for (int i = 0; i < in->num_shapes; i++) {
+            const crt_shape& sh = in->shapes[i];
+            if (sh.type == CRT_INSTANCED) {
+                if (sh.inner < 0 || sh.inner >= in->num_shapes) { delete r; return CRT_E_INVALID; }
+                if (in->shapes[sh.inner].type == CRT_INSTANCED) { delete r; return CRT_E_UNSUPPORTED; }
+            } else if (sh.type == CRT_COMPOUND) {
+                if (sh.first_part < 0 || sh.num_parts < 0 || sh.first_part + sh.num_parts > in->num_shapes) { delete r; return CRT_E_INVALID; }
+                for (int k = 0; k < sh.num_parts; k++) {
+                    const int pt = in->shapes[sh.first_part + k].type;
+                    if (pt == CRT_INSTANCED || pt == CRT_COMPOUND) { delete r; return CRT_E_UNSUPPORTED; }
+                }
+            }
+        }
+    }
     rc = dev_alloc(r, &d_objs, objs.size());
+    if (rc == CRT_OK && any_generic) rc = dev_alloc(r, &d_shapes, (size_t)in->num_shapes);
     if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_vn, 9 * (size_t)in->num_tris);
     if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_vt, 9 * (size_t)in->num_tris);
     if (rc == CRT_OK && any_smooth) rc = dev_alloc(r, &d_nm, 9 * (size_t)ms->num_normal_mats);
@@ -920,6 +955,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     }
     ok = ok && hipMemcpy(d_mats, dev_mats.data(), dev_mats.size() * sizeof(crt_material), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice) == hipSuccess;
+    if (any_generic) ok = ok && hipMemcpy(d_shapes, in->shapes, (size_t)in->num_shapes * sizeof(crt_shape), hipMemcpyHostToDevice) == hipSuccess;
     if (any_smooth) {
         ok = ok && hipMemcpy(d_vn, ms->vertex_normals, 9 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(d_vt, ms->vertex_tangents, 9 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
@@ -931,6 +967,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (!ok) { crt_renderer_destroy(r); return rc != CRT_OK ? rc : CRT_E_HIP; }
     rd.objs = d_objs; rd.mats = d_mats; rd.lights = d_lights;
     rd.vnormals = d_vn; rd.vtangents = d_vt; rd.normal_mats = d_nm;
+    rd.shapes = d_shapes; rd.num_shapes = any_generic ? in->num_shapes : 0;
     rd.num_lights = (int32_t)lights.size();
     rd.has_env = d->has_env_light ? 1 : 0;
     rd.max_depth = d->max_depth;

@@ -259,6 +259,50 @@ SR_HD void sr_fill_simple(const crt_shape* sh, const float* o, const float* d, f
     }
 }
 
+/* ---- one hit on a shape-table object: simple | compound | instanced { simple | compound } -------------- */
+SR_HD void sr_fill_shape_object(const crt_shape* shapes, int num_shapes, int ref, const crt_ray* ray, const crt_hit* hit, int conventions,
+                                crt_shade_rec* sr)
+{
+    if (ref < 0 || ref >= num_shapes) return;
+    const float* o = ray->o;
+    const float* d = ray->d;
+    const float t = hit->t;
+    const crt_shape* sh = &shapes[ref];
+    if (sh->type == CRT_INSTANCED) {                              /* rayIntersectInstanced, instanced.cpp:48-104 */
+        const float* m = sh->inv_xform;
+        float o2[3], d2[3];                                       /* transformRay, util/math.cpp:41-51 */
+        o2[0] = m[0] * o[0] + m[1] * o[1] + m[2] * o[2] + m[3] * 1.0f;
+        o2[1] = m[4] * o[0] + m[5] * o[1] + m[6] * o[2] + m[7] * 1.0f;
+        o2[2] = m[8] * o[0] + m[9] * o[1] + m[10] * o[2] + m[11] * 1.0f;
+        d2[0] = m[0] * d[0] + m[1] * d[1] + m[2] * d[2] + m[3] * 0.0f;
+        d2[1] = m[4] * d[0] + m[5] * d[1] + m[6] * d[2] + m[7] * 0.0f;
+        d2[2] = m[8] * d[0] + m[9] * d[1] + m[10] * d[2] + m[11] * 0.0f;
+        if (sh->inner < 0 || sh->inner >= num_shapes) return;
+        const crt_shape* inner = &shapes[sh->inner];
+        if (inner->type == CRT_COMPOUND) {
+            if (hit->part < 0 || hit->part >= inner->num_parts) return;
+            inner = &shapes[inner->first_part + hit->part];
+        }
+        sr_fill_simple(inner, o2, d2, t, conventions, sr);
+        /* normal = transpose(inv_transform) * (normal, 0), NOT renormalised; hit point on the source ray (:92-100) */
+        const float nx = sr->normal[0], ny = sr->normal[1], nz = sr->normal[2];
+        sr->normal[0] = m[0] * nx + m[4] * ny + m[8] * nz + m[12] * 0.0f;
+        sr->normal[1] = m[1] * nx + m[5] * ny + m[9] * nz + m[13] * 0.0f;
+        sr->normal[2] = m[2] * nx + m[6] * ny + m[10] * nz + m[14] * 0.0f;
+        sr_point_on_ray(sr->hit_point, o, d, t);
+        sr->written |= CRT_SR_HIT_POINT;
+    } else if (sh->type == CRT_COMPOUND) {                        /* rayIntersectCompound, instanced.cpp:155-216: the winning part's record */
+        if (hit->part < 0 || hit->part >= sh->num_parts) return;
+        sr_fill_simple(&shapes[sh->first_part + hit->part], o, d, t, conventions, sr);
+    } else {
+        sr_fill_simple(sh, o, d, t, conventions, sr);
+    }
+    if (conventions && !(sr->written & CRT_SR_DPDU) && (sr->written & (CRT_SR_NORMAL | CRT_SR_BY_CONVENTION))) {
+        sr_tangent_from_normal(sr->dpdu, sr->normal);             /* dpdu where the reference never writes one: normalize(JITTERED_UP x normal) */
+        sr->written |= CRT_SR_BY_CONVENTION;
+    }
+}
+
 /* ---- one hit ------------------------------------------------------------------------------------
  * in: the insertion-order object arrays the scene was built from; ms: mesh shading arrays or null. */
 SR_HD void sr_fill(const crt_scene_input* in, const crt_mesh_shading* ms, const crt_ray* ray, const crt_hit* hit, int conventions,
@@ -320,39 +364,5 @@ SR_HD void sr_fill(const crt_scene_input* in, const crt_mesh_shading* ms, const 
         }
         return;
     }
-    if (ref < 0 || ref >= in->num_shapes) return;
-    const crt_shape* sh = &in->shapes[ref];
-    if (sh->type == CRT_INSTANCED) {                              /* rayIntersectInstanced, instanced.cpp:48-104 */
-        const float* m = sh->inv_xform;
-        float o2[3], d2[3];                                       /* transformRay, util/math.cpp:41-51 */
-        o2[0] = m[0] * o[0] + m[1] * o[1] + m[2] * o[2] + m[3] * 1.0f;
-        o2[1] = m[4] * o[0] + m[5] * o[1] + m[6] * o[2] + m[7] * 1.0f;
-        o2[2] = m[8] * o[0] + m[9] * o[1] + m[10] * o[2] + m[11] * 1.0f;
-        d2[0] = m[0] * d[0] + m[1] * d[1] + m[2] * d[2] + m[3] * 0.0f;
-        d2[1] = m[4] * d[0] + m[5] * d[1] + m[6] * d[2] + m[7] * 0.0f;
-        d2[2] = m[8] * d[0] + m[9] * d[1] + m[10] * d[2] + m[11] * 0.0f;
-        if (sh->inner < 0 || sh->inner >= in->num_shapes) return;
-        const crt_shape* inner = &in->shapes[sh->inner];
-        if (inner->type == CRT_COMPOUND) {
-            if (hit->part < 0 || hit->part >= inner->num_parts) return;
-            inner = &in->shapes[inner->first_part + hit->part];
-        }
-        sr_fill_simple(inner, o2, d2, t, conventions, sr);
-        /* normal = transpose(inv_transform) * (normal, 0), NOT renormalised; hit point on the source ray (:92-100) */
-        const float nx = sr->normal[0], ny = sr->normal[1], nz = sr->normal[2];
-        sr->normal[0] = m[0] * nx + m[4] * ny + m[8] * nz + m[12] * 0.0f;
-        sr->normal[1] = m[1] * nx + m[5] * ny + m[9] * nz + m[13] * 0.0f;
-        sr->normal[2] = m[2] * nx + m[6] * ny + m[10] * nz + m[14] * 0.0f;
-        sr_point_on_ray(sr->hit_point, o, d, t);
-        sr->written |= CRT_SR_HIT_POINT;
-    } else if (sh->type == CRT_COMPOUND) {                        /* rayIntersectCompound, instanced.cpp:155-216: the winning part's record */
-        if (hit->part < 0 || hit->part >= sh->num_parts) return;
-        sr_fill_simple(&in->shapes[sh->first_part + hit->part], o, d, t, conventions, sr);
-    } else {
-        sr_fill_simple(sh, o, d, t, conventions, sr);
-    }
-    if (conventions && !(sr->written & CRT_SR_DPDU) && (sr->written & (CRT_SR_NORMAL | CRT_SR_BY_CONVENTION))) {
-        sr_tangent_from_normal(sr->dpdu, sr->normal);             /* dpdu where the reference never writes one: normalize(JITTERED_UP x normal) */
-        sr->written |= CRT_SR_BY_CONVENTION;
-    }
+    sr_fill_shape_object(in->shapes, in->num_shapes, ref, ray, hit, conventions, sr);
 }

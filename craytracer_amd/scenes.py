@@ -289,6 +289,44 @@ def analytic_scene(rotated=True):
     return sl.to_input()
 
 
+def analytic_render(max_depth=5, rng_seed=2, env_intensity=0.6, samples_in_flight=0, rotated=True, glossy=False):
+    """BASELINE.json configs[1] as a render: the shapes of example_scene.txt:32-78 -- sphere, ground plane, rectangle,
+    triangle, disk, torus(2.0, 0.1) -- plus an instanced box, open cylinder and solid cylinder and the 12-triangle
+    cube, lit by a rectangle light overhead, a small sphere light and a constant sky ("direct light sampling").
+    example_scene.txt itself names no light and its material grammar is the old one, so lights and materials are
+    this repository's.  Returns (SceneInput, RenderDesc, camera position, look point)."""
+    sl = ShapeList()
+    mat_of = []
+    sl.sphere((-2.0, 1.0, 0.0), 1.0); mat_of.append(5 if glossy else 1)
+    sl.plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)); mat_of.append(0)
+    sl.rectangle((1.0, -1.0, -3.0), (4.0, 0.0, 0.0), (0.0, 4.0, -4.0)); mat_of.append(1)
+    sl.triangle([3.0, 0.0, 2.0, 5.0, 0.0, 2.0, 4.0, 2.0, 2.0]); mat_of.append(1)
+    sl.disk((3.0, 3.0, 0.0), _normalize32((1.0, 0.0, 1.0)), 1.0); mat_of.append(2)
+    e = (20.0, 35.0, 10.0) if rotated else (0.0, 0.0, 0.0)
+    s = (1.5, 0.75, 1.25) if rotated else (1.0, 1.0, 1.0)
+    sl.box(inv_transform((-4.0, 0.5, -2.0), s, e), 1.0, 2.0, 1.5); mat_of.append(3)
+    sl.torus(inv_transform((0.0, 0.5, 3.0), (1.0, 1.5, 1.0) if rotated else (1.0, 1.0, 1.0), e), 2.0, 0.1); mat_of.append(6 if glossy else 1)
+    sl.open_cylinder(inv_transform((-1.0, 0.0, -4.0), s, e)); mat_of.append(2)
+    sl.solid_cylinder(inv_transform((5.0, 0.0, -1.0), s, e), 0.5, 1.0); mat_of.append(3)
+    for t in cube_tris((2.0, 0.0, -1.0), 0.5):
+        sl.triangle(t, api.FLAT_TRIANGLE); mat_of.append(2)
+    sl.rectangle((-1.5, 6.0, -1.5), (3.0, 0.0, 0.0), (0.0, 0.0, 3.0)); mat_of.append(4)          # light, facing down (normal = w x h = -y)
+    sl.sphere((-5.0, 2.5, 2.0), 0.4); mat_of.append(7)                                          # sphere light
+    gold = api.METALS["GOLD"]
+    mats = np.array([
+        api.material(api.MAT_MATTE, (0.55, 0.55, 0.55)), api.material(api.MAT_MATTE, (0.5, 0.5, 0.5), sigma=20.0 if glossy else 0.0),
+        api.material(api.MAT_MATTE, (0.6, 0.55, 0.1)), api.material(api.MAT_MATTE, (0.2, 0.35, 0.6)),
+        api.material(api.MAT_EMISSIVE, (1.0, 0.95, 0.85), 14.0),
+        api.material(api.MAT_PLASTIC, (0.5, 0.2, 0.2), ks=(0.3, 0.3, 0.3), uroughness=0.15),
+        api.material(api.MAT_METAL, gold[0], k=gold[1], uroughness=0.1),
+        api.material(api.MAT_EMISSIVE, (0.6, 0.8, 1.0), 25.0),
+    ], api.MATERIAL_DTYPE)
+    si = sl.to_input()
+    env = ((0.7, 0.8, 1.0), env_intensity, 60.0) if env_intensity is not None else None
+    desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=env, samples_in_flight=samples_in_flight)
+    return si, desc, (0.0, 2.5, 9.0), (0.0, 0.5, 0.0)
+
+
 def random_tris(n, seed=1, extent=1.0, size=0.05):
     """n small random triangles in [0, extent]^3 (the soup of SURVEY.md section 6)."""
     rng = np.random.Generator(np.random.PCG64(seed))

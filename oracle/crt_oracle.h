@@ -72,6 +72,7 @@ int   oracle_render(const oracle_scene* scene, const crt_render_desc* d, const c
 /* pieces of the above, exposed for comparison with the reference's own code (tests/test_trace_pieces.py):
  * ShadeRec tail (out = hit_point, normal, wo, dpdu), sampling maps, local basis, Lambertian BSDF */
 void  oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* ray, float t, float* out);
+void  oracle_trace_shade_rec_any(const crt_scene_input* in, const crt_hit* hit, const crt_ray* ray, float* out);
 void  oracle_trace_shade_rec_mesh(const crt_scene_input* in, const crt_mesh_shading* ms, int obj, const crt_ray* ray, float t,
                                   float beta, float gamma, float* out);
 void  oracle_trace_disk(const float* in, float* out);

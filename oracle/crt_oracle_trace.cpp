@@ -164,6 +164,210 @@ void mat3_mult_vec3(vec3 r, const float* a, const vec3 b)
     vec3_copy(r, t);
 }
 
+/* ---- analytic shapes: the reference's intersectors run again on the object that was hit, this time with their record
+ *      writes (rayIntersectSphere + fillShadeRecSphere sphere.cpp:3-86, rayIntersectPlane plane.cpp:4-19, rayIntersectRect rect.cpp:3-52,
+ *      rayIntersectDisk disk.cpp:3-29, rayIntersectAABox generic.cpp:311-404, rayIntersectGenericOpenCylinder + fill :3-80,
+ *      rayIntersectGenericTorus :156-221 (its root comes from the hit: the solver lives in crt_oracle.cpp), rayIntersectInstanced
+ *      instanced.cpp:48-104, rayIntersectCompound :155-216).  Where the reference leaves a field unset the conventions of DESIGN.md
+ *      "a-13" apply: a disk hit from behind keeps the disk's normal, a torus hit outside its phi window is filled as if inside. ---- */
+void getPointOnRay(vec3 r, const vec3 o, const vec3 d, float t) { vec3 disp; vec3_scale(disp, d, t); vec3_add(r, o, disp); }
+
+float simpleShapeRecord(const crt_shape& sh, const vec3 o, const vec3 d, float hit_t, ShadeRec* sr, bool* has_normal, bool* has_dpdu)
+{
+    const float* p = sh.p;
+    switch (sh.type) {
+    case CRT_SPHERE: {
+        const float radius = p[3];
+        float a = vec3_dot(d, d);
+        vec3 origin_to_center, tmp;
+        vec3_sub(origin_to_center, o, p);
+        vec3_scale(tmp, origin_to_center, 2);
+        float b = vec3_dot(tmp, d);
+        float c = vec3_dot(origin_to_center, origin_to_center) - radius * radius;
+        float disc = b * b - 4 * a * c;
+        if (disc < 0.0f) return TMAX;
+        float e = (float)sqrt(disc);
+        float denom = 2 * a;
+        for (int root = 0; root < 2; root++) {
+            float t = root == 0 ? (-b - e) / denom : (-b + e) / denom;
+            if (!(t > K_EPSILON)) continue;
+            vec3 hit_point;
+            getPointOnRay(hit_point, o, d, t);
+            float phi = root == 0 ? atan2f(hit_point[2] - p[2], hit_point[0] - p[0]) : atan2f(hit_point[0] - p[0], hit_point[2] - p[2]);
+            float theta = acosf((hit_point[1] - p[1]) / radius);
+            if (!(fabsf(phi) <= p[6] && theta >= p[4] && theta <= p[5])) continue;
+            vec3_copy(sr->hit_point, hit_point);                   /* fillShadeRecSphere */
+            vec3 hit_point_to_center;
+            vec3_sub(hit_point_to_center, sr->hit_point, p);
+            vec3_normalize(sr->normal, hit_point_to_center);
+            vec3_negate(sr->wo, d);
+            const double phi_max = 2.0 * PI;
+            vec3_assign(sr->dpdu, -phi_max * (hit_point[2] - p[2]), 0.0f, phi_max * (hit_point[0] - p[0]));
+            vec3_normalize(sr->dpdu, sr->dpdu);
+            *has_normal = *has_dpdu = true;
+            return t;
+        }
+        return TMAX;
+    }
+    case CRT_PLANE: {
+        vec3 displacement;
+        vec3_sub(displacement, p, o);
+        float t = vec3_dot(displacement, p + 3) / vec3_dot(d, p + 3);
+        if (t > K_EPSILON) {
+            vec3_copy(sr->normal, p + 3);
+            getPointOnRay(sr->hit_point, o, d, t);
+            vec3_negate(sr->wo, d);
+            *has_normal = true;
+            return t;
+        }
+        return TMAX;
+    }
+    case CRT_RECTANGLE: {
+        vec3 displacement, normal;
+        vec3_sub(displacement, p, o);
+        if (vec3_dot(displacement, p + 9) < 0.0f) vec3_negate(normal, p + 9); else vec3_copy(normal, p + 9);
+        float t = vec3_dot(displacement, normal) / vec3_dot(d, normal);
+        if (t > K_EPSILON) {
+            vec3 point;
+            getPointOnRay(point, o, d, t);
+            vec3_sub(displacement, point, p);
+            float u = vec3_dot(displacement, p + 3) / vec3_dot(p + 3, p + 3);
+            if (u >= 0.0f && u <= 1.0f) {
+                float v = vec3_dot(displacement, p + 6) / vec3_dot(p + 6, p + 6);
+                if (v >= 0.0f && v <= 1.0f) {
+                    vec3_normalize(sr->dpdu, p + 3);
+                    vec3_copy(sr->normal, normal);
+                    vec3_copy(sr->hit_point, point);
+                    vec3_negate(sr->wo, d);
+                    if (vec3_dot(sr->wo, sr->normal) < 0.0f) { vec3_negate(sr->normal, sr->normal); vec3_negate(sr->dpdu, sr->dpdu); }
+                    *has_normal = *has_dpdu = true;
+                    return t;
+                }
+            }
+        }
+        return TMAX;
+    }
+    case CRT_DISK: {
+        vec3 displacement;
+        vec3_sub(displacement, p, o);
+        float t = vec3_dot(displacement, p + 3) / vec3_dot(d, p + 3);
+        if (t > K_EPSILON) {
+            vec3 hit_point;
+            getPointOnRay(hit_point, o, d, t);
+            vec3_sub(displacement, hit_point, p);
+            if (vec3_length(displacement) <= p[6]) {
+                vec3_negate(sr->wo, d);
+                if (vec3_dot(sr->wo, p + 3) < 0) vec3_negate(sr->wo, p + 3);      /* disk.cpp:16-19, as written */
+                vec3_copy(sr->normal, p + 3);                      /* front side: the reference's write; back side: the convention */
+                vec3_copy(sr->hit_point, hit_point);
+                *has_normal = true;
+                return t;
+            }
+        }
+        return TMAX;
+    }
+    case CRT_AABOX: {
+        float tx_min, ty_min, tz_min, tx_max, ty_max, tz_max;
+        float a = 1.0f / d[0];
+        if (a >= 0) { tx_min = (p[0] - o[0]) * a; tx_max = (p[3] - o[0]) * a; } else { tx_min = (p[3] - o[0]) * a; tx_max = (p[0] - o[0]) * a; }
+        float b = 1.0f / d[1];
+        if (b >= 0) { ty_min = (p[1] - o[1]) * b; ty_max = (p[4] - o[1]) * b; } else { ty_min = (p[4] - o[1]) * b; ty_max = (p[1] - o[1]) * b; }
+        float c = 1.0f / d[2];
+        if (c >= 0) { tz_min = (p[2] - o[2]) * c; tz_max = (p[5] - o[2]) * c; } else { tz_min = (p[5] - o[2]) * c; tz_max = (p[2] - o[2]) * c; }
+        float t0, t1;
+        int face_in, face_out;
+        if (tx_min > ty_min) { t0 = tx_min; face_in = (a >= 0.0f) ? 0 : 3; } else { t0 = ty_min; face_in = (b >= 0.0f) ? 1 : 4; }
+        if (tz_min > t0) { t0 = tz_min; face_in = (c >= 0.0f) ? 2 : 5; }
+        if (tx_max < ty_max) { t1 = tx_max; face_out = (a >= 0.0f) ? 3 : 0; } else { t1 = ty_max; face_out = (b >= 0.0f) ? 4 : 1; }
+        if (tz_max < t1) { t1 = tz_max; face_out = (c >= 0.0f) ? 5 : 2; }
+        float t_min = TMAX;
+        if (t0 < t1 && t1 > K_EPSILON) {
+            int face;
+            if (t0 > K_EPSILON) { t_min = t0; face = face_in; } else { t_min = t1; face = face_out; }
+            static const float normals[6][3] = { {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1} };   /* getAABoxNormal */
+            vec3_copy(sr->normal, normals[face]);
+            if (vec3_dot(sr->normal, d) > 0.0f) vec3_negate(sr->normal, sr->normal);
+            getPointOnRay(sr->hit_point, o, d, t_min);
+            vec3_negate(sr->wo, d);
+            *has_normal = true;
+        }
+        return t_min;
+    }
+    case CRT_GENERICOPENCYLINDER: {
+        const float half_height = p[0], radius = p[1];
+        float a = d[0] * d[0] + d[2] * d[2];
+        float b = 2 * (o[0] * d[0] + o[2] * d[2]);
+        float c = o[0] * o[0] + o[2] * o[2] - radius * radius;
+        float disc = b * b - 4 * a * c;
+        if (disc < 0.0f) return TMAX;
+        float e = (float)sqrt(disc);
+        float denom = 2 * a;
+        for (int root = 0; root < 2; root++) {
+            float t = root == 0 ? (-b - e) / denom : (-b + e) / denom;
+            if (!(t > K_EPSILON)) continue;
+            vec3 hit_point;
+            getPointOnRay(hit_point, o, d, t);
+            if (!(fabsf(hit_point[1]) <= half_height)) continue;
+            float phi = atan2f(hit_point[0], hit_point[2]);
+            if (!(fabsf(phi) <= p[2])) continue;
+            vec3_negate(sr->wo, d);                                /* fillShadeRecGenericOpenCylinder */
+            vec3_copy(sr->hit_point, hit_point);
+            const int normal_type = (int)p[3];
+            if (normal_type == 2) vec3_assign(sr->normal, (-hit_point[0]) / radius, 0.0f, (-hit_point[2]) / radius);
+            else {
+                vec3_assign(sr->normal, hit_point[0] / radius, 0.0f, hit_point[2] / radius);
+                if (normal_type == 0 && vec3_dot(sr->wo, sr->normal) < 0) vec3_negate(sr->normal, sr->normal);
+            }
+            *has_normal = true;
+            return t;
+        }
+        return TMAX;
+    }
+    case CRT_GENERICTORUS: {
+        const float t = hit_t;                                     /* the smallest root > eps of the quartic, as found by the query */
+        vec3 hit_point;
+        getPointOnRay(hit_point, o, d, t);
+        vec3_copy(sr->hit_point, hit_point);                       /* inside the phi window: generic.cpp:207-217; outside: the convention */
+        float param_squared = p[0] * p[0] + p[1] * p[1];           /* computeGenericTorusNormal */
+        float x = hit_point[0], y = hit_point[1], z = hit_point[2];
+        float sum_squared = x * x + y * y + z * z;
+        sr->normal[0] = 4.0f * x * (sum_squared - param_squared);
+        sr->normal[1] = 4.0f * y * (sum_squared - param_squared + 2.0f * p[0] * p[0]);
+        sr->normal[2] = 4.0f * z * (sum_squared - param_squared);
+        vec3_normalize(sr->normal, sr->normal);
+        vec3_negate(sr->wo, d);
+        if (vec3_dot(sr->wo, sr->normal) < 0) vec3_negate(sr->normal, sr->normal);
+        *has_normal = true;
+        return t;
+    }
+    default: return TMAX;
+    }
+}
+
+void intersectShapeRecord(const crt_scene_input* in, const crt_shape& sh, const crt_ray& ray, const crt_hit& hit, ShadeRec* sr,
+                          bool* has_normal, bool* has_dpdu)
+{
+    if (sh.type == CRT_INSTANCED) {
+        const float* m = sh.inv_xform;                             /* transformRay, util/math.cpp:41-51 */
+        vec3 o, d;
+        for (int r = 0; r < 3; r++) {
+            o[r] = m[4 * r] * ray.o[0] + m[4 * r + 1] * ray.o[1] + m[4 * r + 2] * ray.o[2] + m[4 * r + 3] * 1.0f;
+            d[r] = m[4 * r] * ray.d[0] + m[4 * r + 1] * ray.d[1] + m[4 * r + 2] * ray.d[2] + m[4 * r + 3] * 0.0f;
+        }
+        const crt_shape* inner = &in->shapes[sh.inner];
+        if (inner->type == CRT_COMPOUND) inner = &in->shapes[inner->first_part + hit.part];
+        simpleShapeRecord(*inner, o, d, hit.t, sr, has_normal, has_dpdu);
+        vec3 n;                                                    /* transpose(inv_transform) * (normal, 0), instanced.cpp:92-99 */
+        for (int c = 0; c < 3; c++) n[c] = m[c] * sr->normal[0] + m[4 + c] * sr->normal[1] + m[8 + c] * sr->normal[2] + m[12 + c] * 0.0f;
+        vec3_copy(sr->normal, n);
+        getPointOnRay(sr->hit_point, ray.o, ray.d, hit.t);
+    } else if (sh.type == CRT_COMPOUND) {
+        simpleShapeRecord(in->shapes[sh.first_part + hit.part], ray.o, ray.d, hit.t, sr, has_normal, has_dpdu);
+    } else {
+        simpleShapeRecord(sh, ray.o, ray.d, hit.t, sr, has_normal, has_dpdu);
+    }
+}
+
 /* ShadeRec tail of the intersector that produced `hit` */
 void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hit& hit)
 {
@@ -207,14 +411,14 @@ void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hi
             vec3_negate(sr->normal, sr->normal);
             vec3_negate(sr->dpdu, sr->dpdu);
         }
-    } else {                                                       /* SPHERE: fillShadeRecSphere */
-        const float* p = in->shapes[ref].p;                        /* center, radius */
-        vec3 hit_point_to_center;
-        vec3_sub(hit_point_to_center, sr->hit_point, p);
-        vec3_normalize(sr->normal, hit_point_to_center);
-        const double phi_max = 2.0 * PI;
-        vec3_assign(sr->dpdu, -phi_max * (sr->hit_point[2] - p[2]), 0.0f, phi_max * (sr->hit_point[0] - p[0]));
-        vec3_normalize(sr->dpdu, sr->dpdu);
+    } else {                                                       /* every other kind: the hit object's own intersector, re-run */
+        bool has_normal = false, has_dpdu = false;
+        intersectShapeRecord(in, in->shapes[ref], ray, hit, sr, &has_normal, &has_dpdu);
+        if (!has_dpdu) {                                           /* shared convention: dpdu where the reference writes none */
+            vec3 c;
+            vec3_cross(c, JITTERED_UP, sr->normal);
+            vec3_normalize(sr->dpdu, c);
+        }
     }
 }
 
@@ -1021,9 +1225,7 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
         const crt_material& mat = d->materials[d->obj_material[i]];
         if (type == CRT_SMOOTH_TRIANGLE && !(d->mesh_shading && d->mesh_shading->vertex_normals && d->mesh_shading->vertex_tangents &&
                                              d->mesh_shading->normal_mat_index && d->mesh_shading->normal_mats)) return -1;
-        if (type != CRT_TRIANGLE && type != CRT_FLAT_TRIANGLE && type != CRT_SMOOTH_TRIANGLE && type != CRT_RECTANGLE && type != CRT_SPHERE &&
-            type != CRT_DISK) return -1;
-        if (type == CRT_DISK && mat.type != CRT_MAT_EMISSIVE) return -1;
+        if (type < 0 || type > CRT_SMOOTH_TRIANGLE) return -1;
         /* EMISSIVE on FLAT / SMOOTH triangles: a MeshLight in the reference, with zero power (preprocessLights has no MESHLIGHT case)
          * and not sampleable by estimateDirect (trace.h:311-313): emits when found, never chosen */
         if ((type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) && mat.type == CRT_MAT_EMISSIVE) {
@@ -1094,6 +1296,17 @@ void oracle_trace_shade_rec(const crt_scene_input* in, int obj, const crt_ray* r
     crt_hit hit; hit.t = t; hit.obj = obj; hit.part = 0; hit.beta = hit.gamma = 0.0f;
     ShadeRec sr; memset(&sr, 0, sizeof sr);
     fillShadeRec(S, &sr, *ray, hit);
+    memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
+}
+/* any object kind: out = hit_point, normal, wo, dpdu (with the conventions applied where the reference writes nothing) */
+void oracle_trace_shade_rec_any(const crt_scene_input* in, const crt_hit* hit, const crt_ray* ray, float* out)
+{
+    crt_render_desc d; memset(&d, 0, sizeof d);
+    d.objects = in;
+    Setup S; S.scene = 0; S.d = &d; S.seed = 0;
+    triangleSetup(&S, in);
+    ShadeRec sr; memset(&sr, 0, sizeof sr);
+    fillShadeRec(S, &sr, *ray, *hit);
     memcpy(out, sr.hit_point, 12); memcpy(out + 3, sr.normal, 12); memcpy(out + 6, sr.wo, 12); memcpy(out + 9, sr.dpdu, 12);
 }
 void oracle_trace_disk(const float* in, float* out) { mapSampleToDisk(out, in); }

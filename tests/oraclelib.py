@@ -76,6 +76,8 @@ def _load_oracle(path):
                                     C.c_uint32, C.c_uint32, vp, C.c_int]
         L.oracle_trace_shade_rec.argtypes = [C.POINTER(api.CrtSceneInput), C.c_int, vp, C.c_float, vp]
         L.oracle_trace_shade_rec.restype = None
+        L.oracle_trace_shade_rec_any.argtypes = [C.POINTER(api.CrtSceneInput), vp, vp, vp]
+        L.oracle_trace_shade_rec_any.restype = None
         L.oracle_trace_shade_rec_mesh.argtypes = [C.POINTER(api.CrtSceneInput), C.POINTER(api.CrtMeshShading), C.c_int, vp, C.c_float,
                                                   C.c_float, C.c_float, vp]
         L.oracle_trace_shade_rec_mesh.restype = None

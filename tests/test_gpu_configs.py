@@ -71,6 +71,47 @@ def test_c2_analytic_1080p(accel):
     sc.close()
 
 
+def test_c2_analytic_rendered_1080p():
+    """BASELINE.json configs[1] as a RENDER: the analytic shapes of example_scene.txt (sphere, plane, rectangle, triangle, disk,
+    torus) with an instanced box, open and solid cylinder and a cube mesh, direct light sampling (rectangle + sphere light, constant
+    sky), 1920 x 1080, binary BVH, one MI355X.  The whole frame at 2 spp against oracle_render on the host cores: pixels that
+    differ are counted (device libm in the phi / theta windows of sphere, cylinder and torus: class T4) and bounded by 0.1 %;
+    then the configuration's 64 spp, timed."""
+    import time
+    si, desc, pos, look = scenes.analytic_render(max_depth=5, rng_seed=64)
+    built = api.BuiltScene(si, api.ACCEL_BVH)
+    scene = api.Scene(built)
+    assert scene.traverse_mode() == api.TRAVERSE_EXACT
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 0.9, 1920, 1080)
+    r = api.Renderer(scene, desc, cam, flm)
+    r.render(2)
+    got, ns = r.read()
+    t0 = time.perf_counter()
+    want = ol.OracleScene(si, built=built).render(desc, cam, flm, 0, 2, nthreads=THREADS)
+    cpu_s = time.perf_counter() - t0
+    assert ns == 2 and np.isfinite(got).all() and got.max() > 0
+    differ = (got != want).any(axis=2)
+    print("C2 render parity: %d of %d pixels differ from the oracle (libm seam class T4)" % (int(differ.sum()), differ.size))
+    assert differ.mean() <= 1e-3
+    rmse = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)) / 2)
+    assert rmse <= 1e-2 * float(want.mean() / 2), rmse                # "final images match within a stated RMSE": 1 % of the mean radiance
+    r.reset(0)
+    t0 = time.perf_counter()
+    r.render(64)
+    gpu_s = time.perf_counter() - t0
+    big, ns = r.read()
+    st = r.stats()
+    r.close(); scene.close()
+    print("C2 render: 1920x1080, 64 spp in %.3f s = %.1f samples/s/pixel on the GPU; oracle on %d threads %.2f samples/s/pixel"
+          % (gpu_s, 64 / gpu_s, THREADS, 2 / cpu_s))
+    assert ns == 64 and np.isfinite(big).all()
+    assert abs(big.mean() / 64 - want.mean() / 2) < 0.03 * (want.mean() / 2)
+    img = api.image_from_color_buffer(big, ns)
+    assert img.shape == (1080, 1920, 3) and 20 < img.mean() < 235
+    assert st["rays_shadow"] > 0
+
+
 def test_c1_cornell_rendered_512x512_16spp():
     """BASELINE.json configs[0] as a render: cornell_box.txt with its materials, 512 x 512, 16 spp, uniform grid,
     path-traced by crt_renderer_* and by the oracle on the host cores: the two colour buffers are bit-identical.
@@ -119,8 +160,11 @@ def test_c3_metal_mesh_1080p():
     r.close()
     want = ol.OracleScene(si, built=built).render(desc, cam, small, 0, 2, nthreads=THREADS)
     assert np.isfinite(got).all() and got.max() > 0
-    same = (got == want).all(axis=2).mean()
-    assert same >= 0.999, same
+    differ = (got != want).any(axis=2)
+    same = 1.0 - differ.mean()
+    # no libm seam on this path (triangles only; the glossy lobes' exp / log are the double functions rounded once on both sides,
+    # cosf / sinf are crt_libm.h's): every pixel must have the oracle's bits
+    assert differ.sum() == 0, "%d of %d pixels differ from the oracle" % (int(differ.sum()), differ.size)
     full = api.make_film(cam, 1.2, 1920, 1080)
     r = api.Renderer(scene, desc, cam, full)
     r.render(1)
@@ -130,8 +174,16 @@ def test_c3_metal_mesh_1080p():
     gpu_s = time.perf_counter() - t0
     big, ns = r.read()
     st = r.stats()
-    r.close(); scene.close()
+    r.close()
     print("C3 render: 1920x1080, 8 spp in %.3f s = %.1f samples/s/pixel; small image %.5f bit-identical" % (gpu_s, 8 / gpu_s, same))
     assert ns == 8 and np.isfinite(big).all()
     assert abs(big.mean() / 8 - got.mean() / 2) < 0.05 * (got.mean() / 2)
+    # the full 1080p frame against the oracle, where the oracle is affordable: every pixel, 1 spp
+    want_full = ol.OracleScene(si, built=built).render(desc, cam, full, 0, 1, nthreads=THREADS)
+    r = api.Renderer(scene, desc, cam, full)
+    r.render(1)
+    one, _ = r.read()
+    r.close(); scene.close()
+    d1 = (one != want_full).any(axis=2)
+    assert d1.sum() == 0, "1080p, 1 spp: %d of %d pixels differ from the oracle" % (int(d1.sum()), d1.size)
     assert st["rays_shadow"] < st["rays_closest"]                   # the metal takes no direct-light sample

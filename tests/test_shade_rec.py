@@ -202,3 +202,38 @@ def test_argument_checks():
     bad.obj_ref[0] = 999
     cb = bad.c_struct()
     assert L.crt_fill_shade_rec(C.byref(cb), None, None, _p(rays), _p(hits), 2, 0, _p(out)) == -1
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("rotated", [False, True])
+def test_oracle_restatement_against_the_reference(rotated):
+    """The oracle's own fillShadeRec (oracle/crt_oracle_trace.cpp: it re-runs the hit object's intersector, a different
+    route from the product's "from t") gives the reference's hit_point / normal / wo / dpdu wherever the reference
+    writes them, and agrees with the product's conventions where it does not."""
+    si = shapes_scene(rotated)
+    rs = ol.RefScene(si, api.ACCEL_NONE)
+    order, _ = rs.order()
+    final_of = {int(i): k for k, i in enumerate(order)}
+    rays = scenes.random_rays(40000, np.float32([-6, -1.5, -6]), np.float32([6, 5, 6]), seed=41 + rotated)
+    hits = rs.intersect(rays)
+    conv = api.fill_shade_rec(si, rays, hits, conventions=True)
+    L, R = ol.oracle(), ol.ref()
+    cin = si.c_struct()
+    n = 0
+    for i in np.nonzero(hits["obj"] >= 0)[0]:
+        obj = int(hits["obj"][i])
+        want = np.zeros(17, np.float32)
+        R.ref_shade_rec_full(rs.h, final_of[obj], _p(rays[i]), _p(want), MARK)
+        got = np.zeros(12, np.float32)
+        L.oracle_trace_shade_rec_any(C.byref(cin), _p(hits[i:i + 1]), _p(rays[i]), _p(got))
+        compound = si.obj_type[obj] == api.COMPOUND or (si.obj_type[obj] == api.INSTANCED and
+                                                         si.shapes[si.shapes[si.obj_ref[obj]]["inner"]]["type"] == api.COMPOUND)
+        for name, g, w in (("hit_point", got[0:3], want[0:3]), ("normal", got[3:6], want[3:6]), ("wo", got[6:9], want[12:15]),
+                           ("dpdu", got[9:12], want[6:9])):
+            bit = dict((f[0], f[3]) for f in FIELDS)[name]
+            if int(conv["written"][i]) & bit:                      # the reference writes it (test above): oracle == reference
+                assert ol.same_bits(g, w), (name, g, w)
+            elif not compound or name in ("normal", "dpdu"):       # convention territory: oracle == product
+                assert ol.same_bits(g, conv[name][i]), (name, g, conv[name][i])
+        n += 1
+    assert n > 20000
