@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--node-compression", default=None, choices=["on", "off"],
+                    help="walk the 64-byte conservative node copy (default: the library's default)")
     ap.add_argument("--binning", default="on", choices=["on", "off"],
                     help="the library's ray binning step (inside the timed region); off = arrival order")
     ap.add_argument("--accel", default="bvh4", choices=["bvh4", "bvh", "grid"],
@@ -331,6 +333,8 @@ def main():
     built = api.BuiltScene(si, accel, sah=(args.builder == "sah"))
     sc = api.Scene(built, local_rank)
     sc.set_ray_binning(args.binning == "on")
+    if args.node_compression is not None:
+        sc.set_node_compression(args.node_compression == "on")
     build_s = time.time() - t0
     n_tris = si.num_obj
 
@@ -402,12 +406,14 @@ def main():
     tris_per_ray = cnt["prims_tested"] / n
     io_bytes = 28 + 5 if shadow else 24 + 20          # shadow: ray + light_dist in, t + occluded out
 
+    compressed_nodes = args.accel == "bvh4" and args.node_compression != "off"
+
     def algorithmic_bytes(nodes, tris):
         """SURVEY.md 8(d), NO-CACHE model: every node visit and every triangle test charged as if it came from HBM.
         24 (ray in) + 20 (hit out) + one QBVH node per visit + 36 + 4 per triangle tested; a node visit reads 112 of
         the node's 128 bytes (6 plane rows + the child words), so 112 is charged, not SURVEY's planning value 128."""
-        if args.accel == "bvh4":
-            return io_bytes + 112 * nodes + 40 * tris
+        if args.accel == "bvh4":                       # 64: one record of the conservative node copy (the default walk)
+            return io_bytes + (64 if compressed_nodes else 112) * nodes + 40 * tris
         if args.accel == "bvh":                        # 32-byte nodes
             return io_bytes + 32 * nodes + 40 * tris
         return io_bytes + 8 * nodes + 44 * tris        # grid: nodes = cells walked, 8 B of cell_start; + 4 B item index per object
@@ -508,6 +514,7 @@ def main():
                    "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
                    if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),
                    "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "builder": args.builder,
+                   "node_format": "64-byte conservative copy (4 x 16 B per visit)" if compressed_nodes else "128-byte nodes (7 x 16 B per visit)",
                    "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum, "src_hash": shash, "scene_build_s": round(build_s, 2)},
         "roofline": roofline(kname, avg_kernel_ms, float(np.mean(bin_ms)), nodes_per_ray, tris_per_ray, tkey, checksum, rays_per_launch),
     }
@@ -538,6 +545,8 @@ def main():
             built_ref = api.BuiltScene(si, accel, sah=False)
             sc_ref = api.Scene(built_ref, local_rank)
             sc_ref.set_ray_binning(args.binning == "on")
+            if args.node_compression is not None:
+                sc_ref.set_node_compression(args.node_compression == "on")
             r_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
             sc_ref.enable_counters(True)
             sc_ref.reset_counters()

@@ -151,7 +151,7 @@ EXPORTS = [
     "crt_scene_file_load", "crt_scene_file_get", "crt_scene_file_free", "crt_env_world_radius",
     "crt_build_scene", "crt_build_scene_ex", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
-    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning",
+    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning", "crt_scene_set_node_compression",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_fill_shade_rec",
@@ -196,6 +196,7 @@ def lib():
     L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
     L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.crt_scene_set_ray_binning.argtypes = [vp, C.c_int]
+    L.crt_scene_set_node_compression.argtypes = [vp, C.c_int]
     f3 = C.POINTER(C.c_float)
     L.crt_camera_init.argtypes = [C.POINTER(CrtCamera), C.c_int, C.c_float, C.c_float]
     L.crt_camera_look_at.argtypes = [C.POINTER(CrtCamera), f3, f3, f3]
@@ -708,6 +709,9 @@ class Scene:
 
     def set_ray_binning(self, on=True):
         _check(lib().crt_scene_set_ray_binning(self._h, 1 if on else 0), "crt_scene_set_ray_binning")
+
+    def set_node_compression(self, on=True):
+        _check(lib().crt_scene_set_node_compression(self._h, 1 if on else 0), "crt_scene_set_node_compression")
 
     def traverse_mode(self):
         m = C.c_int()

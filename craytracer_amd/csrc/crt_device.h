@@ -34,6 +34,7 @@
  */
 struct DevScene {
     const float4* nodes4;
+    const uint4* cnodes4;        /* 64-byte conservative copy of nodes4 (4 x uint4 per node), or a dummy */
     const float4* objs;          /* CRT_OBJ_STRIDE float4 per object */
     const crt_shape* shapes;
     const float4* nodes2;

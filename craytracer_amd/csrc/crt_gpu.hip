@@ -12,6 +12,7 @@
 
 #include <string.h>
 #include <stdio.h>
+#include <math.h>
 #include <vector>
 #include <new>
 #include <mutex>
@@ -67,9 +68,11 @@ struct crt_scene {
     int depth4, depth2;       /* levels of the QBVH / BVH */
     int mode;                 /* requested crt_traverse_mode */
     bool count;
+    bool compress;            /* walk the 64-byte conservative copy of the QBVH nodes where that is allowed (see crt_scene_set_node_compression) */
+    bool cnodes_valid;        /* the copy exists (every node box was finite) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
+    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
     unsigned long long* d_counters;
     Scratch own;              /* allocated by crt_scene_create (perm may grow) */
     Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
@@ -214,7 +217,7 @@ int upload(void** dst, const std::vector<T>& v)
 void free_scene(crt_scene* s)
 {
     if (!s) return;
-    void* ptrs[] = { s->d_nodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
+    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
                      s->d_bnodes2, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
                      s->own.bin_hist, s->own.bin_cursor, s->own.perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -353,7 +356,8 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid) return launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false, true>, la, st, true, na);
+                         return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
@@ -366,7 +370,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, true);
+                         return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
@@ -491,6 +496,68 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 q[7] = make_float4(af, 0.0f, 0.0f, 0.0f);
             }
         }
+        /* 64-byte conservative copy of the nodes (crt_kernels.h "compressed nodes"): per node a frame (origin, scale per axis) and per
+         * child and plane one byte, rounded OUTWARD and checked in double, so that every compressed box contains the node's box */
+        std::vector<uint32_t> cn4;
+        bool cn_ok = desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0;
+        if (cn_ok) {
+            cn4.assign((size_t)desc->num_nodes4 * 16, 0u);
+            for (int i = 0; i < desc->num_nodes4 && cn_ok; i++) {
+                const crt_bvh4_node& nd = desc->nodes4[i];
+                float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
+                bool valid[4], any = false;
+                for (int c = 0; c < 4; c++) {
+                    valid[c] = nd.type[c] == -1 || nd.type[c] > 0;
+                    if (!valid[c]) continue;
+                    for (int k = 0; k < 3; k++) {
+                        const float mn = nd.bbox[4 * k + c], mx = nd.bbox[12 + 4 * k + c];
+                        if (!(fabsf(mn) < 1.0e30f) || !(fabsf(mx) < 1.0e30f)) cn_ok = false;     /* NaN / inf / huge: no compressed copy for this scene */
+                        if (mn > mx) valid[c] = false;                                            /* an inverted box is never hit: keep it that way */
+                        if (mn < lo[k]) lo[k] = mn;
+                        if (mx > hi[k]) hi[k] = mx;
+                    }
+                    any = any || valid[c];
+                }
+                if (!cn_ok) break;
+                if (!any) { lo[0] = lo[1] = lo[2] = 0.0f; hi[0] = hi[1] = hi[2] = 0.0f; }
+                float scale[3];
+                for (int k = 0; k < 3; k++) {
+                    if (hi[k] < lo[k]) { lo[k] = 0.0f; hi[k] = 0.0f; }
+                    float sc = (float)(((double)hi[k] - (double)lo[k]) / 255.0);
+                    while ((double)lo[k] + 255.0 * (double)sc < (double)hi[k]) sc = nextafterf(sc, CRT_TMAX);
+                    scale[k] = sc;
+                }
+                uint32_t* q = &cn4[(size_t)i * 16];
+                memcpy(&q[0], &lo[0], 4); memcpy(&q[1], &lo[1], 4); memcpy(&q[2], &lo[2], 4);
+                memcpy(&q[3], &scale[0], 4); memcpy(&q[4], &scale[1], 4); memcpy(&q[5], &scale[2], 4);
+                for (int k = 0; k < 3; k++) {
+                    uint32_t lo_word = 0, hi_word = 0;
+                    for (int c = 0; c < 4; c++) {
+                        int qlo = 255, qhi = 0;                        /* empty / inverted child: an inverted compressed box */
+                        if (valid[c]) {
+                            const double mn = nd.bbox[4 * k + c], mx = nd.bbox[12 + 4 * k + c], o = lo[k], sc = scale[k];
+                            if (sc > 0.0) {
+                                qlo = (int)floor((mn - o) / sc); if (qlo > 255) qlo = 255; if (qlo < 0) qlo = 0;
+                                while (qlo > 0 && o + qlo * sc > mn) qlo--;
+                                qhi = (int)ceil((mx - o) / sc); if (qhi < 0) qhi = 0; if (qhi > 255) qhi = 255;
+                                while (qhi < 255 && o + qhi * sc < mx) qhi++;
+                                if (o + qlo * sc > mn || o + qhi * sc < mx) cn_ok = false;      /* cannot happen (scale was rounded up); checked anyway */
+                            } else { qlo = 0; qhi = 0; }
+                        }
+                        lo_word |= (uint32_t)qlo << (8 * c);
+                        hi_word |= (uint32_t)qhi << (8 * c);
+                    }
+                    q[6 + k] = lo_word; q[9 + k] = hi_word;
+                }
+                for (int c = 0; c < 4; c++)
+                    q[12 + c] = nd.type[c] == -1 ? (((unsigned)(desc->nodes4[nd.child[c]].axis & 0x03) << 28) | (unsigned)nd.child[c])
+                                                 : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
+            }
+            if (!cn_ok) cn4.clear();
+        }
+        s->cnodes_valid = cn_ok;
+        s->compress = true;
+
         std::vector<float4> n2;
         if (desc->accel == CRT_ACCEL_BVH) {
             n2.resize((size_t)desc->num_nodes2 * 2);
@@ -536,7 +603,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             if (cs.back() > 0) ci.assign(desc->cell_items, desc->cell_items + cs.back());
         }
 
-        if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK ||
+        if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK ||
             (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK) {
             free_scene(s);
@@ -579,6 +646,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
 
     DevScene& dv = s->dev;
     dv.nodes4 = (const float4*)s->d_nodes4;
+    dv.cnodes4 = (const uint4*)s->d_cnodes4;
     dv.objs = (const float4*)s->d_objs;
     dv.shapes = (const crt_shape*)s->d_shapes;
     dv.nodes2 = (const float4*)s->d_nodes2;
@@ -622,6 +690,13 @@ int crt_scene_set_traverse_mode(crt_scene* s, int mode)
     if (mode == CRT_TRAVERSE_EXACT && s->dev.accel == CRT_ACCEL_BVH4 && CRT_STACK_PER_LEVEL_EXACT * s->depth4 + 1 > CRT_STACK_MAX)
         return CRT_E_TOOBIG;                             /* one frame marker per level on top of the pending siblings */
     s->mode = mode;
+    return CRT_OK;
+}
+int crt_scene_set_node_compression(crt_scene* s, int on)
+{
+    if (!s) return CRT_E_INVALID;
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->compress = on != 0;
     return CRT_OK;
 }
 int crt_scene_set_ray_binning(crt_scene* s, int on)

@@ -212,6 +212,75 @@ CRT_DEV void box4_keys_fast2(v2f nx, v2f ny, v2f nz, v2f fx, v2f fy, v2f fz,
                         __builtin_fminf(__builtin_fminf(tx_max.y, ty_max.y), tz_max.y));
 }
 
+/* ---- compressed nodes ---------------------------------------------------------------------------
+ * A second, 64-byte copy of every QBVH node (built on the host in crt_scene_create, checked in double):
+ *   c0 = origin.x origin.y origin.z scale.x     c1 = scale.y scale.z lo_x[4] lo_y[4]
+ *   c2 = lo_z[4] hi_x[4] hi_y[4] hi_z[4]        c3 = the four child words (as in the full node)
+ * plane = origin + byte * scale, bytes rounded outward, so each compressed box CONTAINS the node's box.  A visit reads
+ * 4 x 16 bytes per lane instead of 7 -- the walk is bound by how many lane-loads the L1 takes per clock,
+ * not by bytes.  The slab distances come out of one fma per plane, moved outward by a margin that covers every rounding
+ * on the way (8 ulp of |a| + 255 |b|; analysis in DESIGN.md), so t0 <= the reference's t0 and t1 >= the reference's t1:
+ * the walk visits a SUPERSET of the reference's nodes in the reference's order.  What it finds is the same: a ray that
+ * hits a primitive passes through the primitive's padded box (K_FLAT_AABB = 1e-3 against roundings of 1e-6) and so
+ * through every box above it in the reference's own test; a subtree visited only because its box was widened holds
+ * no hit.  Used for the best-t-pruned closest-hit walk and the any-hit walk of waves whose rays are all `clean`
+ * (no inf / NaN in the slab arithmetic); everything else reads the full nodes.
+ * Key = t0 (conservative): "origin inside the box" needs no special value, t0 < eps <= any hit's t. */
+CRT_DEV void cnode_axis(float origin, float scale, float o, float inv, float* a_near, float* a_far, float* b)
+{
+    const float a = (origin - o) * inv;
+    *b = scale * inv;
+    const float m = __builtin_fmaf(255.0f, fabsf(*b), fabsf(a)) * 4.76837158203125e-07f;      /* 2^-21 */
+    *a_near = a - m;
+    *a_far = a + m;
+}
+CRT_DEV float cnode_key(float tnx, float tny, float tnz, float tfx, float tfy, float tfz)
+{
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float t1 = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+    return ((t0 < t1) && (t1 > CRT_K_EPSILON)) ? t0 : CRT_TMAX;
+}
+#define CRT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xFFu))       /* v_cvt_f32_ubyteN */
+/* keys of the four children of compressed node `nb` (byte offset); sx / sy / sz: direction component >= 0 */
+CRT_DEV void cnode_keys(const uint4* cnodes, unsigned nb, const DRay& r, float ia, float ib, float ic, bool sx, bool sy, bool sz,
+                        float* k0, float* k1, float* k2, float* k3, uint4* words)
+{
+    const char* cb = reinterpret_cast<const char*>(cnodes);
+    const uint4 c0 = *reinterpret_cast<const uint4*>(cb + nb);
+    const uint4 c1 = *reinterpret_cast<const uint4*>(cb + (nb + 16u));
+    const uint4 c2 = *reinterpret_cast<const uint4*>(cb + (nb + 32u));
+    *words = *reinterpret_cast<const uint4*>(cb + (nb + 48u));
+    float anx, afx, bx, any_, afy, by, anz, afz, bz;
+    cnode_axis(__uint_as_float(c0.x), __uint_as_float(c0.w), r.ox, ia, &anx, &afx, &bx);
+    cnode_axis(__uint_as_float(c0.y), __uint_as_float(c1.x), r.oy, ib, &any_, &afy, &by);
+    cnode_axis(__uint_as_float(c0.z), __uint_as_float(c1.y), r.oz, ic, &anz, &afz, &bz);
+    const unsigned qnx = sx ? c1.z : c2.y, qfx = sx ? c2.y : c1.z;
+    const unsigned qny = sy ? c1.w : c2.z, qfy = sy ? c2.z : c1.w;
+    const unsigned qnz = sz ? c2.x : c2.w, qfz = sz ? c2.w : c2.x;
+    const v2f bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+    const v2f anx2 = {anx, anx}, afx2 = {afx, afx}, any2 = {any_, any_}, afy2 = {afy, afy}, anz2 = {anz, anz}, afz2 = {afz, afz};
+    {
+        const v2f tnx = __builtin_elementwise_fma(v2f{CRT_UB(qnx, 0), CRT_UB(qnx, 1)}, bx2, anx2);
+        const v2f tfx = __builtin_elementwise_fma(v2f{CRT_UB(qfx, 0), CRT_UB(qfx, 1)}, bx2, afx2);
+        const v2f tny = __builtin_elementwise_fma(v2f{CRT_UB(qny, 0), CRT_UB(qny, 1)}, by2, any2);
+        const v2f tfy = __builtin_elementwise_fma(v2f{CRT_UB(qfy, 0), CRT_UB(qfy, 1)}, by2, afy2);
+        const v2f tnz = __builtin_elementwise_fma(v2f{CRT_UB(qnz, 0), CRT_UB(qnz, 1)}, bz2, anz2);
+        const v2f tfz = __builtin_elementwise_fma(v2f{CRT_UB(qfz, 0), CRT_UB(qfz, 1)}, bz2, afz2);
+        *k0 = cnode_key(tnx.x, tny.x, tnz.x, tfx.x, tfy.x, tfz.x);
+        *k1 = cnode_key(tnx.y, tny.y, tnz.y, tfx.y, tfy.y, tfz.y);
+    }
+    {
+        const v2f tnx = __builtin_elementwise_fma(v2f{CRT_UB(qnx, 2), CRT_UB(qnx, 3)}, bx2, anx2);
+        const v2f tfx = __builtin_elementwise_fma(v2f{CRT_UB(qfx, 2), CRT_UB(qfx, 3)}, bx2, afx2);
+        const v2f tny = __builtin_elementwise_fma(v2f{CRT_UB(qny, 2), CRT_UB(qny, 3)}, by2, any2);
+        const v2f tfy = __builtin_elementwise_fma(v2f{CRT_UB(qfy, 2), CRT_UB(qfy, 3)}, by2, afy2);
+        const v2f tnz = __builtin_elementwise_fma(v2f{CRT_UB(qnz, 2), CRT_UB(qnz, 3)}, bz2, anz2);
+        const v2f tfz = __builtin_elementwise_fma(v2f{CRT_UB(qfz, 2), CRT_UB(qfz, 3)}, bz2, afz2);
+        *k2 = cnode_key(tnx.x, tny.x, tnz.x, tfx.x, tfy.x, tfz.x);
+        *k3 = cnode_key(tnx.y, tny.y, tnz.y, tfx.y, tfy.y, tfz.y);
+    }
+}
+
 /* Linear pass over objects[first, last) -- the non-grid loops of intersectTest
  * (intersect.h:387-395,:403-411) and the NONE branch (:416-432): strict `<`. */
 template <bool TRI_ONLY, bool COUNT>
@@ -345,7 +414,7 @@ struct RayFeed {
  * the marker (all of the node's children done) folds the node's result into the parent's:
  * `if (t < min_t) min_t = t` (bvh4.h:366-370).  The hit record that survives this chain of strict
  * comparisons is the first-found global minimum, which best_t / best track as in the pruned walk. */
-template <bool TRI_ONLY, bool COUNT, bool EXACT = false>
+template <bool TRI_ONLY, bool COUNT, bool EXACT = false, bool COMPRESSED = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
@@ -393,6 +462,8 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                 clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
                         fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
                         ia != 0.0f && ib != 0.0f && ic != 0.0f;
+                /* compressed nodes: (origin - o) * (1/d) and 255 * scale * (1/d) must stay far from overflow (boxes are < 1e30) */
+                if (COMPRESSED) clean = clean && fabsf(ia) < 1.0e6f && fabsf(ib) < 1.0e6f && fabsf(ic) < 1.0e6f;
                 best_t = CRT_TMAX;
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
                 st.sp = 0;
@@ -408,8 +479,19 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
                     /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
-                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
                     const int ax2 = (int)((cur >> 28) & 3u);
+                    float k0, k1, k2, k3;
+                    unsigned w0, w1, w2, w3;
+                    if (COUNT) c_nodes++;
+                    if (COMPRESSED && wave_clean) {
+                        uint4 wds;
+                        cnode_keys(sc.cnodes4, (cur & CRT_NODE_MASK) << 6, ray, ia, ib, ic, onx == 0u, ony == 16u, onz == 32u, &k0, &k1, &k2, &k3, &wds);
+                        w0 = wds.x; w1 = wds.y; w2 = wds.z; w3 = wds.w;
+                        /* keep the child words of the one 16-byte load: without this the compiler merges them with the full-node
+                         * branch's words as a select of ADDRESSES and loads the four words again, one dword each, after the keys */
+                        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                    } else {
+                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
                     const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
                     const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
                     const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
@@ -418,10 +500,8 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
                     const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
                     const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
-                    if (COUNT) c_nodes++;
                     if (EXACT) { st.push(CRT_FRAME_MARK, cur_min); cur_min = CRT_TMAX; }      /* a new node visit opens: bvh4.h:354 */
-                    float k0, k1, k2, k3;
-                    if (wave_clean) {
+                    if (wave_clean && !COMPRESSED) {
                         box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
                                         ray, ia, ib, ic, &k0, &k1);
                         box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
@@ -432,8 +512,9 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                         k2 = box4_key_sse(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
                         k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
                     }
-                    const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
-                    const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
+                    w0 = __float_as_uint(q6.x); w1 = __float_as_uint(q6.y);
+                    w2 = __float_as_uint(q6.z); w3 = __float_as_uint(q6.w);
+                    }
                     const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
                     /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
                     const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
@@ -498,7 +579,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
  * (intersect.h:470-485).  Same order; bound is the constant light_dist; first t < light_dist
  * in traversal order ends the walk (so the reported t is the reference's, quirk (5)).
  * ===================================================================================== */
-template <bool TRI_ONLY, bool COUNT>
+template <bool TRI_ONLY, bool COUNT, bool COMPRESSED = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchArgs la)
 {
     __shared__ unsigned s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
@@ -535,6 +616,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                 clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
                         fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
                         ia != 0.0f && ib != 0.0f && ic != 0.0f;
+                if (COMPRESSED) clean = clean && fabsf(ia) < 1.0e6f && fabsf(ib) < 1.0e6f && fabsf(ic) < 1.0e6f;
                 result = CRT_TMAX;
                 st.sp = 0;
                 cur = sc.root_word;
@@ -548,8 +630,22 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
             if (walking) {
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
-                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
                     const int ax2 = (int)((cur >> 28) & 3u);
+                    if (COUNT) c_nodes++;
+                    float k0, k1, k2, k3;
+                    unsigned w0, w1, w2, w3;
+                    bool v0, v1, v2, v3;
+                    if (COMPRESSED && wave_clean) {
+                        /* conservative entry distances (t0 <= the reference's): visited iff the reference's test could pass,
+                         * bvh4.h:450 with box_t = t0 or "origin inside" (t0 < eps) */
+                        uint4 wds;
+                        cnode_keys(sc.cnodes4, (cur & CRT_NODE_MASK) << 6, ray, ia, ib, ic, onx == 0u, ony == 16u, onz == 32u, &k0, &k1, &k2, &k3, &wds);
+                        w0 = wds.x; w1 = wds.y; w2 = wds.z; w3 = wds.w;
+                        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                        const float bound = ld > CRT_K_EPSILON ? ld : CRT_K_EPSILON;
+                        v0 = k0 < bound; v1 = k1 < bound; v2 = k2 < bound; v3 = k3 < bound;
+                    } else {
+                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
                     const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
                     const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
                     const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
@@ -558,9 +654,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                     const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
                     const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
                     const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
-                    if (COUNT) c_nodes++;
-                    float k0, k1, k2, k3;
-                    if (wave_clean) {
+                    if (wave_clean && !COMPRESSED) {
                         box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
                                         ray, ia, ib, ic, &k0, &k1);
                         box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
@@ -572,10 +666,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                         k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
                     }
                     /* bvh4.h:450: bbox_t < light_dist || (less_than && bbox_t < TMAX); key = -inf encodes the latter */
-                    const bool v0 = k0 < ld || k0 == ninf, v1 = k1 < ld || k1 == ninf;
-                    const bool v2 = k2 < ld || k2 == ninf, v3 = k3 < ld || k3 == ninf;
-                    const unsigned w0 = __float_as_uint(q6.x), w1 = __float_as_uint(q6.y);
-                    const unsigned w2 = __float_as_uint(q6.z), w3 = __float_as_uint(q6.w);
+                    v0 = k0 < ld || k0 == ninf; v1 = k1 < ld || k1 == ninf;
+                    v2 = k2 < ld || k2 == ninf; v3 = k3 < ld || k3 == ninf;
+                    w0 = __float_as_uint(q6.x); w1 = __float_as_uint(q6.y);
+                    w2 = __float_as_uint(q6.z); w3 = __float_as_uint(q6.w);
+                    }
                     const bool p2 = ((pbits >> ax2) & 1u) != 0u;
                     const bool vC = p2 ? v2 : v3, vD = p2 ? v3 : v2;
                     const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;

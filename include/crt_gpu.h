@@ -220,6 +220,13 @@ void crt_host_free(void* p);
  * exactly as before and its result is written at its own index, so outputs do not change. */
 int  crt_scene_set_ray_binning(crt_scene* s, int on);
 
+/* Compressed node copy (experiment switch; see DESIGN.md for its default).  No counterpart in the reference.  For QBVH
+ * scenes crt_scene_create also keeps a 64-byte conservative copy of every node (per axis an origin and a scale, per
+ * child and plane one byte rounded outward, checked in double); the best-t-pruned closest-hit walk may read that copy
+ * instead of the 128-byte nodes.  Every compressed box contains the node's box, so the walk visits a superset of the
+ * nodes in the same order and returns the same hit records bit for bit. */
+int  crt_scene_set_node_compression(crt_scene* s, int on);
+
 /* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose
  * H2D copy, kernel and D2H copy are pipelined on two streams; returns when hits[] is complete. */
 int  crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits);

@@ -164,12 +164,23 @@ def test_counters_match_the_oracles_walk(scene, mode):
     built = api.BuiltScene(si, api.ACCEL_BVH4)
     sc = api.Scene(built, 0)
     sc.set_traverse_mode(mode)
+    sc.set_node_compression(False)       # the 128-byte nodes: the reference's boxes, the oracle's walk step for step
     sc.enable_counters(True)
     sc.reset_counters()
-    sc.intersect(rays)
+    g_full = sc.intersect(rays)
     c = sc.counters()
     o = ol.OracleScene(si, api.ACCEL_BVH4)
     _, oc = o.intersect(rays, mode=mode, counters=True)
+    if scene == "blobs" and mode == api.TRAVERSE_PRUNED:
+        # the 64-byte conservative node copy: boxes that contain the reference's, so a superset of the oracle's walk (a
+        # few per cent more boxes and triangles), in the same order, and the same hit records bit for bit
+        sc.set_node_compression(True)
+        sc.reset_counters()
+        g_comp = sc.intersect(rays)
+        cc = sc.counters()
+        assert ol.same_bits(g_comp, g_full)
+        assert oc["nodes_visited"] <= cc["nodes_visited"] <= 1.1 * oc["nodes_visited"]
+        assert oc["prims_tested"] <= cc["prims_tested"] <= 1.1 * oc["prims_tested"]
     assert c["rays_closest"] == len(rays)
     if scene == "blobs":
         assert c["nodes_visited"] == oc["nodes_visited"] and c["prims_tested"] == oc["prims_tested"]
