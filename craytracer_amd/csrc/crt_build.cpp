@@ -283,6 +283,9 @@ void build4(Builder& B, NodeCountCache& ncc, int first, int count, int self, int
 #define CRT_SAH_BINS 16
 #endif
 const int SAH_BINS = CRT_SAH_BINS;
+#ifndef CRT_SAH_LEAF
+#define CRT_SAH_LEAF 4                              /* objects per leaf of the SAH tree (the reference's rule: 4) */
+#endif
 const int SAH_MAX_DEPTH = 20;                       /* levels; the pruned walk allows 21 (3 * depth + 1 <= 64) */
 
 inline float box_area(const Box& b)
@@ -302,7 +305,7 @@ inline Box box_empty()
 inline int levels_needed(int count)                 /* levels a median-split QBVH needs for `count` objects */
 {
     int levels = 1;
-    long long cap = 16;                             /* one node: 4 children of <= 4 objects */
+    long long cap = 4 * CRT_SAH_LEAF;               /* one node: 4 children of <= CRT_SAH_LEAF objects */
     while (cap < count) { cap *= 4; levels++; }
     return levels;
 }
@@ -409,20 +412,20 @@ int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count
             nd.bbox[c] = nd.bbox[4 + c] = nd.bbox[8 + c] = 1.0f;
             nd.bbox[12 + c] = nd.bbox[16 + c] = nd.bbox[20 + c] = -1.0f;
         }
-        if (cnt > 4) { nd.type[c] = -1; nd.child[c] = -1; }
+        if (cnt > CRT_SAH_LEAF) { nd.type[c] = -1; nd.child[c] = -1; }
         else { nd.type[c] = (int8_t)cnt; nd.child[c] = first + start[c]; }
     }
     const bool fork = depth < 2 && B.max_threads > 1 && count > 65536;
     if (fork) {
         std::vector<std::vector<crt_bvh4_node> > sub(4);
         std::vector<std::thread> th;
-        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
             std::vector<crt_bvh4_node>* dst = &sub[c];
             const int f = first + start[c], cnt = child_cnt[c];
             th.emplace_back([&B, dst, f, cnt, depth]() { build4_sah(B, *dst, f, cnt, depth + 1); });
         }
         for (auto& t : th) t.join();
-        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
             const int base = (int)out.size();
             nd.child[c] = base;
             for (crt_bvh4_node n : sub[c]) {
@@ -431,7 +434,7 @@ int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count
             }
         }
     } else {
-        for (int c = 0; c < 4; c++) if (child_cnt[c] > 4) {
+        for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
             std::vector<crt_bvh4_node> sub;
             build4_sah(B, sub, first + start[c], child_cnt[c], depth + 1);
             const int base = (int)out.size();

@@ -291,7 +291,10 @@ const unsigned CRT_BIN_MIN_RAYS = 1u << 18;
 const size_t CRT_PERM_PRESIZE = (size_t)1 << 24;      /* 64 MB: ray order for batches up to 2^24 rays, allocated with the scene */
 /* The walks saturate at 4 resident blocks (waves per SIMD) per CU: 691 / 936 / 1 090 / 1 092 Mrays/s at 2 / 3 / 4 / 5
  * (closest hit, courtyard-10M); the any-hit walk, whose 16 KB stack would allow 7, runs 1 904 at 5 against 1 869 at 7. */
-const int CRT_MAX_BLOCKS_PER_CU = 5;
+#ifndef CRT_MAX_BLOCKS
+#define CRT_MAX_BLOCKS 5
+#endif
+const int CRT_MAX_BLOCKS_PER_CU = CRT_MAX_BLOCKS;
 
 /* NOALLOC: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
  * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before. */

@@ -13,11 +13,17 @@
 #include "crt_device.h"
 
 #define CRT_BLOCK      256
+/* LDS part of the per-lane stack.  8-byte entries (closest-hit walks): 14 deep = 28 KB per workgroup, so that FIVE workgroups
+ * are resident per CU -- at 16 deep (32 KB) only four fit in the 160 KB, and the fifth wave per SIMD is worth 8 % (1 813 ->
+ * 1 954 Mrays/s; 12 deep: 1 915, six waves at 80 VGPRs and 12 / 13 deep: 1 844 / 1 854).  4-byte entries (any-hit walks): 16 deep. */
 #ifndef CRT_LDS_DEPTH
-#define CRT_LDS_DEPTH  16
+#define CRT_LDS_DEPTH  14
+#endif
+#ifndef CRT_LDS_DEPTH32
+#define CRT_LDS_DEPTH32 16
 #endif
 #define CRT_OVF_DEPTH  48
-#define CRT_STACK_MAX  (CRT_LDS_DEPTH + CRT_OVF_DEPTH)
+#define CRT_STACK_MAX  (CRT_LDS_DEPTH + CRT_OVF_DEPTH)     /* 62: what crt_scene_create checks tree depths against */
 /* stack entries a QBVH walk can need per tree level: 3 pending siblings, + 1 frame marker in the
  * reference-control-flow (EXACT) walk */
 #define CRT_STACK_PER_LEVEL_PRUNED 3
@@ -92,15 +98,15 @@ struct LaneStack32 {
     int sp;
     CRT_DEV void push(unsigned w)
     {
-        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) lds[sp][threadIdx.x] = w;
-        else if (sp < CRT_STACK_MAX) ovf_push32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride, w);
+        if (__builtin_expect(sp < CRT_LDS_DEPTH32, 1)) lds[sp][threadIdx.x] = w;
+        else if (sp < CRT_STACK_MAX) ovf_push32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH32) * ovf_stride, w);
         sp++;
     }
     CRT_DEV unsigned pop()
     {
         sp--;
-        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) return lds[sp][threadIdx.x];
-        return ovf_pop32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride);
+        if (__builtin_expect(sp < CRT_LDS_DEPTH32, 1)) return lds[sp][threadIdx.x];
+        return ovf_pop32(ovf_word, (size_t)(sp - CRT_LDS_DEPTH32) * ovf_stride);
     }
 };
 
@@ -322,6 +328,26 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #ifndef CRT_TRI_STEP
 #define CRT_TRI_STEP 1
 #endif
+#ifndef CRT_WALK_WAVES_N
+#define CRT_WALK_WAVES_N 0        /* n > 0: register budget of the QBVH walk kernels for n waves per SIMD */
+#endif
+#if CRT_WALK_WAVES_N
+#define CRT_WALK_WAVES __attribute__((amdgpu_waves_per_eu(CRT_WALK_WAVES_N, CRT_WALK_WAVES_N)))
+#else
+#define CRT_WALK_WAVES
+#endif
+#ifndef CRT_FUSE_LEAF_SHADOW
+#define CRT_FUSE_LEAF_SHADOW 1    /* the same in the any-hit walk: +3.6 % */
+#endif
+#ifndef CRT_PROBE_NO_FALLBACK
+#define CRT_PROBE_NO_FALLBACK 0   /* register-pressure probe only: results are wrong for rays that are not `clean` */
+#endif
+#ifndef CRT_FUSE_LEAF
+#define CRT_FUSE_LEAF 1           /* a node step that descends into a leaf tests the leaf's first object in the same iteration: +3 % */
+#endif
+#ifndef CRT_VOTE
+#define CRT_VOTE 0                /* experiment: k > 0 = one kind of step per wave iteration, switch when the other kind outnumbers k : 1 */
+#endif
 
 CRT_DEV unsigned lane_rank(unsigned long long mask)
 {
@@ -415,7 +441,7 @@ struct RayFeed {
  * `if (t < min_t) min_t = t` (bvh4.h:366-370).  The hit record that survives this chain of strict
  * comparisons is the first-found global minimum, which best_t / best track as in the pruned walk. */
 template <bool TRI_ONLY, bool COUNT, bool EXACT = false, bool COMPRESSED = false>
-__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchArgs la)
+__global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
@@ -444,6 +470,9 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
 
     RayFeed<false> feed;
     feed.start(la);
+#if CRT_VOTE
+    bool phase_node = true;
+#endif
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
         if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN) {
@@ -474,8 +503,22 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
             if (__ballot(alive && !clean) != 0ull) wave_clean = false;
         }
         if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
+#if CRT_VOTE
+        /* one kind of step per iteration, chosen by the wave: lanes of the other kind keep their item and wait */
+        bool step_now = true;
+        {
+            const bool act = alive && walking;
+            const bool inner = !(cur & CRT_LEAF_BIT);
+            const unsigned nn = (unsigned)__popcll(__ballot(act && inner)), nl = (unsigned)__popcll(__ballot(act && !inner));
+            if (phase_node) { if (nn * CRT_VOTE < nl || nn == 0u) phase_node = false; }
+            else { if (nl * CRT_VOTE < nn || nl == 0u) phase_node = true; }
+            step_now = inner == phase_node;
+        }
+#else
+        const bool step_now = true;
+#endif
         if (alive) {
-            if (walking) {
+            if (walking && step_now) {
                 bool need_pop = true;
                 if (!(cur & CRT_LEAF_BIT)) {
                     /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
@@ -483,7 +526,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     float k0, k1, k2, k3;
                     unsigned w0, w1, w2, w3;
                     if (COUNT) c_nodes++;
-                    if (COMPRESSED && wave_clean) {
+                    if (COMPRESSED && (CRT_PROBE_NO_FALLBACK || wave_clean)) {
                         uint4 wds;
                         cnode_keys(sc.cnodes4, (cur & CRT_NODE_MASK) << 6, ray, ia, ib, ic, onx == 0u, ony == 16u, onz == 32u, &k0, &k1, &k2, &k3, &wds);
                         w0 = wds.x; w1 = wds.y; w2 = wds.z; w3 = wds.w;
@@ -526,10 +569,51 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
                     if (s2k < thr) st.push(s2w, s2k);
                     if (s1k < thr) st.push(s1w, s1k);
                     if (s0k < thr) { cur = s0w; need_pop = false; }
-                } else {
+                }
+#if CRT_FUSE_LEAF
+                /* a lane whose node step went straight into a leaf tests that leaf's first object in the same iteration */
+                if (cur & CRT_LEAF_BIT) {
+                    need_pop = true;
+#else
+                else {
+#endif
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
-#if CRT_TRI_STEP
+#if CRT_TRI_STEP == 2
+                    /* two objects of the leaf per step, in array order (bvh4.h:374-383); both records are fetched before the
+                     * first is tested, so the step waits for memory once */
+                    if (TRI_ONLY) {
+                        if (count > 0) {
+                            const float4* rec = sc.objs + (size_t)first * CRT_OBJ_STRIDE;
+                            const float4* rec2 = rec + (count > 1 ? CRT_OBJ_STRIDE : 0);
+                            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2];
+                            const float4 b0 = rec2[0], b1 = rec2[1], b2 = rec2[2];
+                            DHit h; h.part = 0;
+                            float t = dev_tri(a0, a1, a2, ray, &h.beta, &h.gamma);
+                            h.obj = __float_as_int(a2.y);
+                            if (COUNT) c_prims++;
+                            if (t < best_t) { best_t = t; best = h; }
+                            if (EXACT && t < cur_min) cur_min = t;
+                            if (count > 1) {
+                                t = dev_tri(b0, b1, b2, ray, &h.beta, &h.gamma);
+                                h.obj = __float_as_int(b2.y);
+                                if (COUNT) c_prims++;
+                                if (t < best_t) { best_t = t; best = h; }
+                                if (EXACT && t < cur_min) cur_min = t;
+                            }
+                        }
+                        if (count > 2) { cur = CRT_LEAF_BIT | ((unsigned)(count - 2) << 28) | (unsigned)(first + 2); need_pop = false; }
+                    } else {
+                        if (count > 0) {
+                            DHit h;
+                            const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
+                            if (COUNT) c_prims++;
+                            if (t < best_t) { best_t = t; best = h; }
+                            if (EXACT && t < cur_min) cur_min = t;
+                        }
+                        if (count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
+                    }
+#elif CRT_TRI_STEP
                     /* one object of the leaf per step, in array order (bvh4.h:374-383): lanes that sit
                      * in leaves of different sizes stay in step with the lanes that test boxes */
                     if (count > 0) {
@@ -580,9 +664,9 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_closest(DevScene sc, LaunchA
  * in traversal order ends the walk (so the reported t is the reference's, quirk (5)).
  * ===================================================================================== */
 template <bool TRI_ONLY, bool COUNT, bool COMPRESSED = false>
-__global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchArgs la)
+__global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevScene sc, LaunchArgs la)
 {
-    __shared__ unsigned s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
+    __shared__ unsigned s_stack[CRT_LDS_DEPTH32][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack32 st;
     st.lds = s_stack;
@@ -680,7 +764,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh4_shadow(DevScene sc, LaunchAr
                     if (s2v) st.push(s2w);
                     if (s1v) st.push(s1w);
                     if (s0v) { cur = s0w; need_pop = false; }
-                } else {
+                }
+#if CRT_FUSE_LEAF_SHADOW
+                if (cur & CRT_LEAF_BIT) {
+                    need_pop = true;
+#else
+                else {
+#endif
                     /* one object of the leaf per step, in array order (bvh4.h:464-472) */
                     const int count = (int)((cur >> 28) & 7u);
                     const int first = (int)(cur & 0x0FFFFFFFu);
