@@ -933,6 +933,14 @@ int crt_scene_get_counters(crt_scene* s, crt_counters* out)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost));
     out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_visited = h[2]; out->prims_tested = h[3];
+#if CRT_DIAG
+    {
+        unsigned long long d[9];
+        HIPCHK(hipMemcpy(d, s->d_counters + 8, sizeof d, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[diag] wave-iterations %llu  alive/it %.2f  walking/it %.2f  node lanes/it %.2f  object lanes/it %.2f  stalled/it %.2f  iterations with a node step %.3f  with an object step %.3f\n",
+                d[0], (double)d[1] / d[0], (double)d[8] / d[0], (double)d[2] / d[0], (double)d[3] / d[0], (double)d[5] / d[0], (double)d[6] / d[0], (double)d[7] / d[0]);
+    }
+#endif
     return CRT_OK;
 }
 int crt_scene_reset_counters(crt_scene* s)

@@ -325,9 +325,6 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #ifndef CRT_REFILL_MIN_SHADOW
 #define CRT_REFILL_MIN_SHADOW 32  /* any-hit walks are short: 28..36 measure the same, 16 and 48 are 6..9 % slower */
 #endif
-#ifndef CRT_TRI_STEP
-#define CRT_TRI_STEP 1
-#endif
 #ifndef CRT_WALK_WAVES_N
 #define CRT_WALK_WAVES_N 0        /* n > 0: register budget of the QBVH walk kernels for n waves per SIMD */
 #endif
@@ -336,17 +333,20 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #else
 #define CRT_WALK_WAVES
 #endif
+#ifndef CRT_XCD_RANGES
+#define CRT_XCD_RANGES 0
+#endif
 #ifndef CRT_FUSE_LEAF_SHADOW
 #define CRT_FUSE_LEAF_SHADOW 1    /* the same in the any-hit walk: +3.6 % */
 #endif
 #ifndef CRT_PROBE_NO_FALLBACK
 #define CRT_PROBE_NO_FALLBACK 0   /* register-pressure probe only: results are wrong for rays that are not `clean` */
 #endif
-#ifndef CRT_FUSE_LEAF
-#define CRT_FUSE_LEAF 1           /* a node step that descends into a leaf tests the leaf's first object in the same iteration: +3 % */
+#ifndef CRT_DIAG
+#define CRT_DIAG 0                /* diagnostic build: per-iteration lane statistics of the closest-hit walk into counters[8..] */
 #endif
-#ifndef CRT_VOTE
-#define CRT_VOTE 0                /* experiment: k > 0 = one kind of step per wave iteration, switch when the other kind outnumbers k : 1 */
+#ifndef CRT_PENDING_LEAF
+#define CRT_PENDING_LEAF 1
 #endif
 
 CRT_DEV unsigned lane_rank(unsigned long long mask)
@@ -367,17 +367,48 @@ struct RayFeed {
     unsigned res_pos, res_cnt;        /* wave-uniform: next unread slot / slots in the current claim */
     bool empty;                       /* wave-uniform: the queue has nothing more for this wave */
     unsigned pre_ri; DRay pre_ray; float pre_ld;
-
+#if CRT_XCD_RANGES
+    /* The queue (in the binning step's order: pieces of space) is cut into 8 contiguous ranges with one head each (8 words 32
+     * bytes apart in the queue-head line).  A wave starts in the range of its workgroup's XCD (workgroups are dealt to the 8
+     * XCDs round-robin) and moves to the next range when its own is drained, so each XCD's L2 mostly serves one piece of the
+     * scene; which wave traces a ray changes nothing about the ray's result. */
+    unsigned rng, adv, rng_len;       /* wave-uniform: current range, ranges found drained so far, slots per range (multiple of 64) */
+    CRT_DEV void claim(const LaunchArgs& la)
+    {
+        if ((threadIdx.x & 63) == 0) pend = atomicAdd(la.queue_head + rng * 8u, 64u);
+    }
+    CRT_DEV unsigned claimed_base(const LaunchArgs& la)      /* slot index of the claim in `pend`, or la.n when everything is drained */
+    {
+        for (;;) {
+            const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend);
+            const unsigned beg = rng * rng_len;
+            const unsigned end = beg + rng_len < la.n ? beg + rng_len : la.n;
+            if (beg < la.n && off < end - beg) return beg + off;
+            if (++adv >= 8u) return la.n;
+            rng = (rng + 1u) & 7u;
+            claim(la);
+        }
+    }
+    CRT_DEV unsigned claim_limit(const LaunchArgs& la, unsigned base)
+    {
+        const unsigned end = rng * rng_len + rng_len < la.n ? rng * rng_len + rng_len : la.n;
+        return end - base;
+    }
+#else
     CRT_DEV void claim(const LaunchArgs& la)
     {
         if ((threadIdx.x & 63) == 0) pend = atomicAdd(la.queue_head, 64u);
     }
+    CRT_DEV unsigned claimed_base(const LaunchArgs& la) { return (unsigned)__builtin_amdgcn_readfirstlane((int)pend); }
+    CRT_DEV unsigned claim_limit(const LaunchArgs& la, unsigned base) { return la.n - base; }
+#endif
     CRT_DEV void swap_in(const LaunchArgs& la)
     {
-        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pend);
+        const unsigned base = claimed_base(la);
         res_pos = 0;
-        res_cnt = base < la.n ? (la.n - base < 64u ? la.n - base : 64u) : 0u;
-        if (res_cnt == 0u) { empty = true; return; }
+        if (base >= la.n) { res_cnt = 0; empty = true; return; }
+        const unsigned lim = claim_limit(la, base);
+        res_cnt = lim < 64u ? lim : 64u;
         const unsigned lane = threadIdx.x & 63;
         if (lane < res_cnt) {
             const unsigned idx = base + lane;
@@ -390,6 +421,10 @@ struct RayFeed {
     CRT_DEV void start(const LaunchArgs& la)
     {
         pend = 0; res_pos = res_cnt = 0; empty = false;
+#if CRT_XCD_RANGES
+        rng = blockIdx.x & 7u; adv = 0u;
+        rng_len = (((la.n + 7u) >> 3) + 63u) & ~63u;
+#endif
         pre_ri = 0; pre_ld = 0.0f;
         pre_ray.ox = pre_ray.oy = pre_ray.oz = 0.0f; pre_ray.dx = pre_ray.dy = pre_ray.dz = 1.0f;
         claim(la);
@@ -443,6 +478,9 @@ struct RayFeed {
 template <bool TRI_ONLY, bool COUNT, bool EXACT = false, bool COMPRESSED = false>
 __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
+    /* PENDING: the conservative-node walk keeps the leaf it is testing in a register of its own (`pl`) and walks on while
+     * the leaf's remaining objects are tested, one per iteration, next to the node steps (see the loop below). */
+    constexpr bool PENDING = COMPRESSED && !EXACT && CRT_PENDING_LEAF;
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
@@ -455,6 +493,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
 
     bool alive = false;
     unsigned ri = 0, cur = 0;
+    unsigned pl = 0;              /* PENDING: leaf word whose objects are being tested (count field 0 = none) */
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
     bool px = true, walking = false;
@@ -468,10 +507,85 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
     float cur_min = CRT_TMAX;     /* EXACT: min_t of the innermost open node visit */
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
+    /* One node visit of the lane's `cur`: the four keys, then the children that pass are pushed in reverse visiting order and
+     * the first becomes `cur`.  Returns false when no child passes (the lane has to pop). */
+    auto node_step = [&]() __attribute__((always_inline)) -> bool {
+        /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
+        const int ax2 = (int)((cur >> 28) & 3u);
+        float k0, k1, k2, k3;
+        unsigned w0, w1, w2, w3;
+        if (COUNT) c_nodes++;
+        if (COMPRESSED && wave_clean) {
+            uint4 wds;
+            cnode_keys(sc.cnodes4, (cur & CRT_NODE_MASK) << 6, ray, ia, ib, ic, onx == 0u, ony == 16u, onz == 32u, &k0, &k1, &k2, &k3, &wds);
+            w0 = wds.x; w1 = wds.y; w2 = wds.z; w3 = wds.w;
+            /* keep the child words of the one 16-byte load: without this the compiler merges them with the full-node
+             * branch's words as a select of ADDRESSES and loads the four words again, one dword each, after the keys */
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+        } else {
+            const unsigned nb = (cur & CRT_NODE_MASK) << 7;
+            const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
+            const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
+            const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
+            const float4 ny = *reinterpret_cast<const float4*>(nbase + (nb + ony));
+            const float4 fy = *reinterpret_cast<const float4*>(nbase + (nb + ofy));
+            const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
+            const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
+            const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
+            if (EXACT) { st.push(CRT_FRAME_MARK, cur_min); cur_min = CRT_TMAX; }      /* a new node visit opens: bvh4.h:354 */
+            if (wave_clean && !COMPRESSED) {
+                box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
+                                ray, ia, ib, ic, &k0, &k1);
+                box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
+                                ray, ia, ib, ic, &k2, &k3);
+            } else {
+                k0 = box4_key_sse(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
+                k1 = box4_key_sse(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
+                k2 = box4_key_sse(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
+                k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
+            }
+            w0 = __float_as_uint(q6.x); w1 = __float_as_uint(q6.y);
+            w2 = __float_as_uint(q6.z); w3 = __float_as_uint(q6.w);
+        }
+        const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
+        /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
+        const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
+        const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
+        const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
+        const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
+        const float thr = EXACT ? cur_min : best_t;                       /* EXACT: TMAX here, the visit has just opened */
+        if (s3k < thr) st.push(s3w, s3k);
+        if (s2k < thr) st.push(s2w, s2k);
+        if (s1k < thr) st.push(s1w, s1k);
+        if (s0k < thr) { cur = s0w; return true; }
+        return false;
+    };
+    /* the object at objects[first] against the ray: strict `<`, array order (bvh4.h:374-383) */
+    auto object_step = [&](int first) __attribute__((always_inline)) {
+        DHit h;
+        const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
+        if (COUNT) c_prims++;
+        if (t < best_t) { best_t = t; best = h; }
+        if (EXACT && t < cur_min) cur_min = t;                             /* bvh4.h:378-382, the open node's min_t */
+    };
+    /* pops until an entry survives the cull against the nearest hit so far; false = the stack is empty */
+    auto pop_next = [&]() __attribute__((always_inline)) -> bool {
+        while (st.sp > 0) {
+            unsigned w; float key;
+            st.pop(&w, &key);
+            if (EXACT && w == CRT_FRAME_MARK) {                            /* the node visit closes: bvh4.h:366-370 */
+                cur_min = cur_min < key ? cur_min : key;
+                continue;
+            }
+            if (key < (EXACT ? cur_min : best_t)) { cur = w; return true; }
+        }
+        return false;
+    };
+
     RayFeed<false> feed;
     feed.start(la);
-#if CRT_VOTE
-    bool phase_node = true;
+#if CRT_DIAG
+    unsigned d_it = 0, d_alive = 0, d_node = 0, d_obj = 0, d_pop = 0, d_stall = 0, d_nodeit = 0, d_objit = 0, d_walk = 0;
 #endif
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
@@ -497,165 +611,84 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
                 st.sp = 0;
                 cur = sc.root_word;
+                pl = 0u;
                 walking = sc.n_accel > 0;
                 alive = true;
             }
             if (__ballot(alive && !clean) != 0ull) wave_clean = false;
         }
         if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
-#if CRT_VOTE
-        /* one kind of step per iteration, chosen by the wave: lanes of the other kind keep their item and wait */
-        bool step_now = true;
-        {
-            const bool act = alive && walking;
-            const bool inner = !(cur & CRT_LEAF_BIT);
-            const unsigned nn = (unsigned)__popcll(__ballot(act && inner)), nl = (unsigned)__popcll(__ballot(act && !inner));
-            if (phase_node) { if (nn * CRT_VOTE < nl || nn == 0u) phase_node = false; }
-            else { if (nl * CRT_VOTE < nn || nl == 0u) phase_node = true; }
-            step_now = inner == phase_node;
+#if CRT_DIAG
+        if (COUNT) {
+            const bool inner = alive && walking && !(cur & CRT_LEAF_BIT);
+            const bool leafcur = alive && walking && (cur & CRT_LEAF_BIT);
+            const bool plbusy = ((pl >> 28) & 7u) != 0u;
+            const unsigned n_in = (unsigned)__popcll(__ballot(inner));
+            const unsigned n_ob = (unsigned)__popcll(__ballot(alive && (PENDING ? plbusy : leafcur)));
+            d_it++; d_alive += (unsigned)__popcll(__ballot(alive)); d_node += n_in; d_obj += n_ob;
+            d_stall += (unsigned)__popcll(__ballot(leafcur && plbusy));
+            d_walk += (unsigned)__popcll(__ballot(alive && walking));
+            d_nodeit += n_in ? 1u : 0u; d_objit += n_ob ? 1u : 0u;
         }
-#else
-        const bool step_now = true;
 #endif
         if (alive) {
-            if (walking && step_now) {
-                bool need_pop = true;
-                if (!(cur & CRT_LEAF_BIT)) {
-                    /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
-                    const int ax2 = (int)((cur >> 28) & 3u);
-                    float k0, k1, k2, k3;
-                    unsigned w0, w1, w2, w3;
-                    if (COUNT) c_nodes++;
-                    if (COMPRESSED && (CRT_PROBE_NO_FALLBACK || wave_clean)) {
-                        uint4 wds;
-                        cnode_keys(sc.cnodes4, (cur & CRT_NODE_MASK) << 6, ray, ia, ib, ic, onx == 0u, ony == 16u, onz == 32u, &k0, &k1, &k2, &k3, &wds);
-                        w0 = wds.x; w1 = wds.y; w2 = wds.z; w3 = wds.w;
-                        /* keep the child words of the one 16-byte load: without this the compiler merges them with the full-node
-                         * branch's words as a select of ADDRESSES and loads the four words again, one dword each, after the keys */
-                        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
-                    } else {
-                    const unsigned nb = (cur & CRT_NODE_MASK) << 7;
-                    const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
-                    const float4 nx = *reinterpret_cast<const float4*>(nbase + (nb + onx));
-                    const float4 fx = *reinterpret_cast<const float4*>(nbase + (nb + ofx));
-                    const float4 ny = *reinterpret_cast<const float4*>(nbase + (nb + ony));
-                    const float4 fy = *reinterpret_cast<const float4*>(nbase + (nb + ofy));
-                    const float4 nz = *reinterpret_cast<const float4*>(nbase + (nb + onz));
-                    const float4 fz = *reinterpret_cast<const float4*>(nbase + (nb + ofz));
-                    const float4 q6 = *reinterpret_cast<const float4*>(nbase + (nb + 96u));
-                    if (EXACT) { st.push(CRT_FRAME_MARK, cur_min); cur_min = CRT_TMAX; }      /* a new node visit opens: bvh4.h:354 */
-                    if (wave_clean && !COMPRESSED) {
-                        box4_keys_fast2(v2f{nx.x, nx.y}, v2f{ny.x, ny.y}, v2f{nz.x, nz.y}, v2f{fx.x, fx.y}, v2f{fy.x, fy.y}, v2f{fz.x, fz.y},
-                                        ray, ia, ib, ic, &k0, &k1);
-                        box4_keys_fast2(v2f{nx.z, nx.w}, v2f{ny.z, ny.w}, v2f{nz.z, nz.w}, v2f{fx.z, fx.w}, v2f{fy.z, fy.w}, v2f{fz.z, fz.w},
-                                        ray, ia, ib, ic, &k2, &k3);
-                    } else {
-                        k0 = box4_key_sse(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, ray, ia, ib, ic);
-                        k1 = box4_key_sse(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, ray, ia, ib, ic);
-                        k2 = box4_key_sse(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, ray, ia, ib, ic);
-                        k3 = box4_key_sse(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, ray, ia, ib, ic);
-                    }
-                    w0 = __float_as_uint(q6.x); w1 = __float_as_uint(q6.y);
-                    w2 = __float_as_uint(q6.z); w3 = __float_as_uint(q6.w);
-                    }
-                    const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
-                    /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
-                    const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
-                    const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
-                    const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
-                    const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
-                    const float thr = EXACT ? cur_min : best_t;                       /* EXACT: TMAX here, the visit has just opened */
-                    if (s3k < thr) st.push(s3w, s3k);
-                    if (s2k < thr) st.push(s2w, s2k);
-                    if (s1k < thr) st.push(s1w, s1k);
-                    if (s0k < thr) { cur = s0w; need_pop = false; }
+            if (PENDING) {
+                /* Each iteration a lane may take a node step AND test one object.  A leaf reached by the walk moves into `pl`
+                 * (when `pl` is free) and the walk pops on at once; `pl` gives one object per iteration, in array order.
+                 * Objects are therefore tested in exactly the order of the plain walk -- leaves enter `pl` one at a time, in
+                 * walk order, and a second leaf waits in `cur` until the first is finished -- so the nearest hit AND which of
+                 * several equal-t hits is kept are unchanged; only the boxes tested while `pl` still holds objects are culled
+                 * against a nearest hit that is up to three objects stale, i.e. a few more children get pushed (they are culled
+                 * again, against the current value, when popped). */
+                bool need_pop = false;
+                if (walking) {
+                    if (!(cur & CRT_LEAF_BIT)) need_pop = !node_step();
+                    if ((cur & CRT_LEAF_BIT) && !need_pop && ((pl >> 28) & 7u) == 0u) { pl = cur; need_pop = true; }
                 }
-#if CRT_FUSE_LEAF
-                /* a lane whose node step went straight into a leaf tests that leaf's first object in the same iteration */
-                if (cur & CRT_LEAF_BIT) {
-                    need_pop = true;
-#else
-                else {
-#endif
-                    const int count = (int)((cur >> 28) & 7u);
-                    const int first = (int)(cur & 0x0FFFFFFFu);
-#if CRT_TRI_STEP == 2
-                    /* two objects of the leaf per step, in array order (bvh4.h:374-383); both records are fetched before the
-                     * first is tested, so the step waits for memory once */
-                    if (TRI_ONLY) {
-                        if (count > 0) {
-                            const float4* rec = sc.objs + (size_t)first * CRT_OBJ_STRIDE;
-                            const float4* rec2 = rec + (count > 1 ? CRT_OBJ_STRIDE : 0);
-                            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2];
-                            const float4 b0 = rec2[0], b1 = rec2[1], b2 = rec2[2];
-                            DHit h; h.part = 0;
-                            float t = dev_tri(a0, a1, a2, ray, &h.beta, &h.gamma);
-                            h.obj = __float_as_int(a2.y);
-                            if (COUNT) c_prims++;
-                            if (t < best_t) { best_t = t; best = h; }
-                            if (EXACT && t < cur_min) cur_min = t;
-                            if (count > 1) {
-                                t = dev_tri(b0, b1, b2, ray, &h.beta, &h.gamma);
-                                h.obj = __float_as_int(b2.y);
-                                if (COUNT) c_prims++;
-                                if (t < best_t) { best_t = t; best = h; }
-                                if (EXACT && t < cur_min) cur_min = t;
-                            }
-                        }
-                        if (count > 2) { cur = CRT_LEAF_BIT | ((unsigned)(count - 2) << 28) | (unsigned)(first + 2); need_pop = false; }
-                    } else {
-                        if (count > 0) {
-                            DHit h;
-                            const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
-                            if (COUNT) c_prims++;
-                            if (t < best_t) { best_t = t; best = h; }
-                            if (EXACT && t < cur_min) cur_min = t;
-                        }
+                const unsigned pcount = (pl >> 28) & 7u;
+                if (pcount > 0u) {
+                    const unsigned first = pl & 0x0FFFFFFFu;
+                    object_step((int)first);
+                    pl = pcount > 1u ? (CRT_LEAF_BIT | ((pcount - 1u) << 28) | (first + 1u)) : 0u;
+                }
+                if (need_pop) walking = pop_next();
+                if (!walking && ((pl >> 28) & 7u) == 0u) {
+                    linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                    store_hit(la.hits, ri, best_t, best);
+                    if (COUNT) c_rays++;
+                    alive = false;
+                }
+            } else {
+                if (walking) {
+                    bool need_pop = true;
+                    if (!(cur & CRT_LEAF_BIT)) need_pop = !node_step();
+                    /* a lane whose node step went straight into a leaf tests that leaf's first object in the same iteration;
+                     * one object of a leaf per iteration: lanes in leaves of different sizes stay in step with the others */
+                    if (cur & CRT_LEAF_BIT) {
+                        const int count = (int)((cur >> 28) & 7u);
+                        const int first = (int)(cur & 0x0FFFFFFFu);
+                        need_pop = true;
+                        if (count > 0) object_step(first);
                         if (count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
                     }
-#elif CRT_TRI_STEP
-                    /* one object of the leaf per step, in array order (bvh4.h:374-383): lanes that sit
-                     * in leaves of different sizes stay in step with the lanes that test boxes */
-                    if (count > 0) {
-                        DHit h;
-                        const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
-                        if (COUNT) c_prims++;
-                        if (t < best_t) { best_t = t; best = h; }
-                        if (EXACT && t < cur_min) cur_min = t;                         /* bvh4.h:378-382, the open node's min_t */
-                    }
-                    if (count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
-#else
-                    for (int j = 0; j < count; j++) {                                 /* bvh4.h:374-383 */
-                        DHit h;
-                        const float t = dev_object<TRI_ONLY>(sc, first + j, ray, false, &h);
-                        if (COUNT) c_prims++;
-                        if (t < best_t) { best_t = t; best = h; }
-                        if (EXACT && t < cur_min) cur_min = t;
-                    }
-#endif
+                    if (need_pop) walking = pop_next();
                 }
-                if (need_pop) {
-                    walking = false;
-                    while (st.sp > 0) {
-                        unsigned w; float key;
-                        st.pop(&w, &key);
-                        if (EXACT && w == CRT_FRAME_MARK) {                            /* the node visit closes: bvh4.h:366-370 */
-                            cur_min = cur_min < key ? cur_min : key;
-                            continue;
-                        }
-                        if (key < (EXACT ? cur_min : best_t)) { cur = w; walking = true; break; }
-                    }
+                if (!walking) {
+                    linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                    store_hit(la.hits, ri, best_t, best);
+                    if (COUNT) c_rays++;
+                    alive = false;
                 }
-            }
-            if (!walking) {
-                linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-                store_hit(la.hits, ri, best_t, best);
-                if (COUNT) c_rays++;
-                alive = false;
             }
         }
     }
     flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, false);
+#if CRT_DIAG
+    if (COUNT && (threadIdx.x & 63) == 0) {
+        const unsigned v[9] = { d_it, d_alive, d_node, d_obj, d_pop, d_stall, d_nodeit, d_objit, d_walk };
+        for (int k = 0; k < 9; k++) atomicAdd(&sc.counters[8 + k], (unsigned long long)v[k]);
+    }
+#endif
 }
 
 /* =====================================================================================
