@@ -133,7 +133,13 @@ class CrtRenderDesc(C.Structure):
     _fields_ = [("objects", C.c_void_p), ("obj_material", C.c_void_p), ("materials", C.c_void_p), ("num_materials", C.c_int32),
                 ("has_env_light", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_float),
                 ("env_world_radius", C.c_float), ("max_depth", C.c_int32), ("samples_in_flight", C.c_uint32),
-                ("seed", C.c_uint64), ("mesh_shading", C.c_void_p)]
+                ("seed", C.c_uint64), ("mesh_shading", C.c_void_p),
+                ("textures", C.c_void_p), ("num_textures", C.c_int32), ("material_diffuse_tex", C.c_void_p),
+                ("env_map", C.c_int32), ("env_transform", C.c_float * 9), ("row_begin", C.c_int32), ("row_end", C.c_int32)]
+
+
+class CrtTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("comp", C.c_int32), ("is_float", C.c_int32), ("data", C.c_void_p)]
 
 
 class CrtRenderStats(C.Structure):
@@ -154,7 +160,7 @@ EXPORTS = [
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning", "crt_scene_set_node_compression",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
-    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_fill_shade_rec",
+    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_intersect_batch_dev_counted", "crt_shadow_batch_dev_counted", "crt_fill_shade_rec",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
@@ -211,6 +217,8 @@ def lib():
     L.crt_intersect_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.crt_shadow_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.crt_intersect_batch_dev_noalloc.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    L.crt_intersect_batch_dev_counted.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.crt_shadow_batch_dev_counted.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.crt_fill_shade_rec.argtypes = [C.POINTER(CrtSceneInput), vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.crt_scene_enable_counters.argtypes = [vp, C.c_int]
     L.crt_scene_get_counters.argtypes = [vp, C.POINTER(CrtCounters)]
@@ -356,7 +364,11 @@ class RenderDesc:
     """Materials, lights and limits of the restricted path tracer (crt_render_desc).  Keeps the numpy
     arrays alive; `.c` is the ctypes struct."""
 
-    def __init__(self, scene_input, obj_material, materials, max_depth, seed=0, env=None, samples_in_flight=0, mesh_shading=None):
+    def __init__(self, scene_input, obj_material, materials, max_depth, seed=0, env=None, samples_in_flight=0, mesh_shading=None,
+                 textures=None, material_diffuse_tex=None, env_map=None, env_transform=None, rows=None):
+        """textures: list of [h, w, 3] arrays (uint8, or float32 for an EXR-style map); material_diffuse_tex: per material an
+        index into textures or -1; env_map: index of the environment map (needs env); env_transform: 3 x 3; rows: (begin, end)
+        image rows this renderer renders (tile sharding)."""
         self.scene_input = scene_input
         self._in = scene_input.c_struct()
         self.obj_material = np.ascontiguousarray(obj_material, dtype=np.int32)
@@ -378,6 +390,31 @@ class RenderDesc:
         self.mesh_shading = mesh_shading                  # a MeshShading (keeps its arrays alive) or None
         if mesh_shading is not None:
             c.mesh_shading = C.addressof(mesh_shading.c)
+        self.textures = []
+        if textures:
+            self._tex = (CrtTexture * len(textures))()
+            for k, t in enumerate(textures):
+                t = np.ascontiguousarray(t)
+                assert t.ndim == 3 and t.shape[2] in (3, 4) and t.dtype in (np.uint8, np.float32)
+                self.textures.append(t)
+                self._tex[k].height, self._tex[k].width, self._tex[k].comp = t.shape
+                self._tex[k].is_float = 1 if t.dtype == np.float32 else 0
+                self._tex[k].data = t.ctypes.data
+            c.textures = C.addressof(self._tex)
+            c.num_textures = len(textures)
+        self.material_diffuse_tex = None
+        if material_diffuse_tex is not None:
+            self.material_diffuse_tex = np.ascontiguousarray(material_diffuse_tex, dtype=np.int32)
+            assert len(self.material_diffuse_tex) == len(self.materials)
+            c.material_diffuse_tex = _ptr(self.material_diffuse_tex)
+        if env_map is not None:
+            c.env_map = int(env_map) + 1
+        if env_transform is not None:
+            c.env_transform = (C.c_float * 9)(*[float(x) for x in np.asarray(env_transform, np.float32).reshape(9)])
+        self.rows = None
+        if rows is not None:
+            self.rows = (int(rows[0]), int(rows[1]))
+            c.row_begin, c.row_end = self.rows
         self.c = c
 
 
@@ -545,6 +582,8 @@ class Renderer:
     def __init__(self, scene, desc, cam, film):
         self._scene, self._desc = scene, desc             # the C side keeps a pointer to the scene
         self.width, self.height = film.frame_res_width, film.frame_res_height
+        if getattr(desc, "rows", None):                   # a band of the frame: the colour buffer holds these rows only
+            self.height = desc.rows[1] - desc.rows[0]
         self._h = C.c_void_p()
         _check(lib().crt_renderer_create(scene._h, C.byref(desc.c), C.byref(cam), C.byref(film), C.byref(self._h)),
                "crt_renderer_create")
@@ -747,6 +786,13 @@ class Scene:
 
     def shadow_dev(self, d_rays, d_light_dist, n, d_t, d_occ, stream=None):
         _check(lib().crt_shadow_batch_dev(self._h, d_rays, d_light_dist, n, d_t, d_occ, stream), "crt_shadow_batch_dev")
+
+    def intersect_dev_counted(self, d_rays, d_n, n_max, d_hits, stream=None):
+        """crt_intersect_batch_dev_counted: the ray count is the device word at d_n (clamped to n_max)."""
+        _check(lib().crt_intersect_batch_dev_counted(self._h, d_rays, d_n, n_max, d_hits, stream), "crt_intersect_batch_dev_counted")
+
+    def shadow_dev_counted(self, d_rays, d_light_dist, d_n, n_max, d_t, d_occ, stream=None):
+        _check(lib().crt_shadow_batch_dev_counted(self._h, d_rays, d_light_dist, d_n, n_max, d_t, d_occ, stream), "crt_shadow_batch_dev_counted")
 
     def enable_counters(self, on=True):
         _check(lib().crt_scene_enable_counters(self._h, 1 if on else 0), "crt_scene_enable_counters")

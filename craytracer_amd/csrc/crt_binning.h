@@ -46,8 +46,9 @@ __device__ __forceinline__ unsigned bin_cell(const crt_ray* rays, unsigned i, co
     return bin_spread((unsigned)fx) | (bin_spread((unsigned)fy) << 1) | (bin_spread((unsigned)fz) << 2);
 }
 
-__global__ __launch_bounds__(CRT_BIN_BLOCK) void k_bin_hist(const crt_ray* rays, unsigned n, BinGrid g, unsigned* hist)
+__global__ __launch_bounds__(CRT_BIN_BLOCK) void k_bin_hist(const crt_ray* rays, unsigned n, const unsigned* n_dev, BinGrid g, unsigned* hist)
 {
+    if (n_dev) { const unsigned m = *n_dev; n = m < n ? m : n; }     /* counted launch: n is the upper bound */
     __shared__ unsigned h[CRT_BIN_CELLS];
     for (unsigned b = threadIdx.x; b < CRT_BIN_CELLS; b += CRT_BIN_BLOCK) h[b] = 0;
     __syncthreads();
@@ -80,8 +81,9 @@ __global__ __launch_bounds__(CRT_BIN_BLOCK) void k_bin_scan(unsigned* hist, unsi
     for (unsigned k = 0; k < per; k++) { cursor[threadIdx.x * per + k] = run; run += v[k]; hist[threadIdx.x * per + k] = 0; }
 }
 
-__global__ __launch_bounds__(CRT_BIN_BLOCK) void k_bin_scatter(const crt_ray* rays, unsigned n, BinGrid g, unsigned* cursor, unsigned* perm)
+__global__ __launch_bounds__(CRT_BIN_BLOCK) void k_bin_scatter(const crt_ray* rays, unsigned n, const unsigned* n_dev, BinGrid g, unsigned* cursor, unsigned* perm)
 {
+    if (n_dev) { const unsigned m = *n_dev; n = m < n ? m : n; }
     __shared__ unsigned h[CRT_BIN_CELLS];
     for (unsigned b = threadIdx.x; b < CRT_BIN_CELLS; b += CRT_BIN_BLOCK) h[b] = 0;
     __syncthreads();

@@ -338,9 +338,9 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
         }
         HIPCHK(hipEventRecord(lt.ev_bin, stream));
         const unsigned bb = (la.n + CRT_BIN_CHUNK - 1) / CRT_BIN_CHUNK;
-        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, sx.bin_hist);
+        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_hist);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, sx.bin_hist, sx.bin_cursor);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, s->bin_grid, sx.bin_cursor, sx.perm);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_cursor, sx.perm);
         HIPCHK(hipGetLastError());
         la.perm = sx.perm;
     }
@@ -716,7 +716,7 @@ int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
     return CRT_OK;
 }
 
-static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc)
+static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc, const uint32_t* d_n = 0)
 {
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -726,7 +726,7 @@ static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit*
     if (!guard.ok) return CRT_E_HIP;
     LaunchArgs la;
     memset(&la, 0, sizeof la);
-    la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n;
+    la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
     if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st, noalloc) : dispatch_closest<true, false>(s, la, st, noalloc);
     return s->count ? dispatch_closest<false, true>(s, la, st, noalloc) : dispatch_closest<false, false>(s, la, st, noalloc);
@@ -743,8 +743,16 @@ int crt_intersect_batch_dev_noalloc(crt_scene* s, const crt_ray* d_rays, size_t 
     return intersect_dev(s, d_rays, n, d_hits, stream, true);
 }
 
-int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
-                         float* d_t_out, uint8_t* d_occluded_out, void* stream)
+/* Counted launches: the number of rays is read from device memory by the kernels themselves (*d_n, at most n_max), so a
+ * wavefront driver can chain extend -> shade -> shadow launches without the host ever learning the queue sizes. */
+int crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const uint32_t* d_n, size_t n_max, crt_hit* d_hits, void* stream)
+{
+    if (!d_n) return CRT_E_INVALID;
+    return intersect_dev(s, d_rays, n_max, d_hits, stream, false, d_n);
+}
+
+static int shadow_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                      float* d_t_out, uint8_t* d_occluded_out, void* stream, const uint32_t* d_n)
 {
     if (!s || (n > 0 && (!d_rays || !d_light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -753,10 +761,21 @@ int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_lig
     if (!guard.ok) return CRT_E_HIP;
     LaunchArgs la;
     memset(&la, 0, sizeof la);
-    la.rays = d_rays; la.light_dist = d_light_dist; la.t_out = d_t_out; la.occ_out = d_occluded_out; la.n = (unsigned)n;
+    la.rays = d_rays; la.light_dist = d_light_dist; la.t_out = d_t_out; la.occ_out = d_occluded_out; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
     if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st) : dispatch_shadow<true, false>(s, la, st);
     return s->count ? dispatch_shadow<false, true>(s, la, st) : dispatch_shadow<false, false>(s, la, st);
+}
+int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                         float* d_t_out, uint8_t* d_occluded_out, void* stream)
+{
+    return shadow_dev(s, d_rays, d_light_dist, n, d_t_out, d_occluded_out, stream, 0);
+}
+int crt_shadow_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, const uint32_t* d_n, size_t n_max,
+                                 float* d_t_out, uint8_t* d_occluded_out, void* stream)
+{
+    if (!d_n) return CRT_E_INVALID;
+    return shadow_dev(s, d_rays, d_light_dist, n_max, d_t_out, d_occluded_out, stream, d_n);
 }
 
 /* Host-buffer entry points.  The batch is cut into chunks that alternate between two streams,

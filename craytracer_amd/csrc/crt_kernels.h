@@ -42,7 +42,13 @@ struct LaunchArgs {
     float* ovf_key;               /* [CRT_OVF_DEPTH][grid threads] */
     unsigned grid_threads;
     const unsigned* perm;         /* queue slot -> ray index (crt_binning.h), or null: slot == ray index */
+    const unsigned* n_dev;        /* counted launches: the ray count lives on the device (n is then its upper bound), or null */
 };
+/* first statement of every walk kernel: the launch's ray count */
+CRT_DEV void resolve_count(LaunchArgs& la)
+{
+    if (la.n_dev) { const unsigned m = *la.n_dev; la.n = m < la.n ? m : la.n; }
+}
 
 /* ---- per-lane stack ----------------------------------------------------------------
  * Entry = (child word, key) packed in 8 bytes -> one ds_write_b64 / ds_read_b64.  The LDS part is
@@ -478,6 +484,7 @@ struct RayFeed {
 template <bool TRI_ONLY, bool COUNT, bool EXACT = false, bool COMPRESSED = false>
 __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     /* PENDING: the conservative-node walk keeps the leaf it is testing in a register of its own (`pl`) and walks on while
      * the leaf's remaining objects are tested, one per iteration, next to the node steps (see the loop below). */
     constexpr bool PENDING = COMPRESSED && !EXACT && CRT_PENDING_LEAF;
@@ -699,6 +706,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
 template <bool TRI_ONLY, bool COUNT, bool COMPRESSED = false>
 __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     __shared__ unsigned s_stack[CRT_LDS_DEPTH32][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack32 st;
@@ -840,6 +848,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
 template <bool TRI_ONLY, bool COUNT>
 __global__ __launch_bounds__(CRT_BLOCK) void k_none_closest(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_prims = 0;
     for (;;) {
@@ -860,6 +869,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_closest(DevScene sc, LaunchA
 template <bool TRI_ONLY, bool COUNT>
 __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_prims = 0;
     for (;;) {
@@ -896,6 +906,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
 template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
@@ -1048,6 +1059,7 @@ CRT_DEV void grid_step(GridWalk* w)
 template <bool TRI_ONLY, bool COUNT, bool SHADOW>
 __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
 {
+    resolve_count(la);
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
     for (;;) {

@@ -26,6 +26,7 @@
 #include "crt_camera.h"
 #include "crt_libm.h"
 #include "crt_shaderec.h"
+#include "crt_texture.h"
 
 namespace {
 
@@ -393,6 +394,12 @@ struct RenderDev {
     const crt_shape* shapes; int32_t num_shapes;                                  /* plane / disk / box / cylinder / torus / instanced / compound hits */
     int32_t num_lights, has_env, max_depth;
     float env_color[3], env_intensity, env_world_radius;
+    /* textures: Texture records with device texel pointers, Matte.diffuse / Plastic.diffuse per material (-1 = none), texcoords of the
+     * mesh triangles ([tri][6]), and the environment map (EnvLight type TEXTURE) with EnvLight.transform */
+    const crt_texture* tex; const int32_t* mat_tex; const float* vuv;
+    int32_t env_map;                      /* 1 + texture index, 0 = constant colour */
+    float env_xf[9];
+    uint32_t pix_offset;                  /* first pixel of the band this renderer renders (row_begin * width) */
     uint32_t seed_lo, seed_hi, npix;
     crt_camera cam; crt_film film;
     /* per path */
@@ -400,7 +407,9 @@ struct RenderDev {
     /* queues */
     crt_ray* rays[2]; uint32_t* qpath[2]; crt_hit* hits;
     crt_ray* srays; float* sdist; uint32_t* spath; float* scontrib; uint8_t* socc;
-    uint32_t* counters;                   /* [0] rays queued for the next bounce, [1] shadow rays queued */
+    /* queue sizes, all on the device: word 2b = rays queued for bounce b (word 0 = paths of the pass), word 2(b+1)+1 = shadow
+     * rays queued by bounce b; bounce b's shading appends to both with one 64-bit atomic on the pair at word 2(b+1) */
+    uint32_t* counters;
     float* color;                         /* [npix*3] running sum, main.cpp:139-141 */
 };
 
@@ -430,12 +439,30 @@ __device__ __forceinline__ void queue_push2(unsigned long long* counters, bool w
     *shadow_slot = bs + (unsigned)__popcll(ms & below);
 }
 
+/* getEnvLightIncRadiance (lights.cpp:233-248) for a direction already taken through EnvLight.transform */
+__device__ __forceinline__ V3 env_radiance(const RenderDev& rd, const V3& dir)
+{
+    if (rd.env_map == 0) return scale(v3p(rd.env_color), rd.env_intensity);          /* CONSTANT */
+    const crt_texture t = rd.tex[rd.env_map - 1];
+    const float d[3] = { dir.x, dir.y, dir.z };
+    float uv[2], c[3];
+    crt_env_uv(uv, d);
+    crt_tex_color(c, t.width, t.height, t.comp, t.is_float, t.data, uv);
+    return scale(v3p(c), rd.env_intensity);
+}
+/* mat3_mult_vec3(out, env_light->transform, v), trace.h:300,:439 */
+__device__ __forceinline__ V3 env_transform(const RenderDev& rd, const V3& v)
+{
+    return v3(dot(v3p(rd.env_xf), v), dot(v3p(rd.env_xf + 3), v), dot(v3p(rd.env_xf + 6), v));
+}
+
 /* threadFunc's per-pixel head, main.cpp:102-115: two Sampler_getSample values, calcImageCoord, calcCameraRay */
 __global__ __launch_bounds__(256) void k_pt_generate(RenderDev rd, unsigned num_paths, unsigned first_sample)
 {
     const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= num_paths) return;
-    const unsigned pixel = p % rd.npix, sample = first_sample + p / rd.npix;
+    if (p == 0) rd.counters[0] = num_paths;                      /* size of bounce 0's queue */
+    const unsigned pixel = rd.pix_offset + p % rd.npix, sample = first_sample + p / rd.npix;     /* pixel index in the whole frame */
     const float i0 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_IMAGE), i1 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_IMAGE + 1);
     const float l0 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_LENS), l1 = crt_rng(rd.seed_lo, rd.seed_hi, pixel, sample, DIM_LENS + 1);
     crt_ray ray;
@@ -449,8 +476,11 @@ __global__ __launch_bounds__(256) void k_pt_generate(RenderDev rd, unsigned num_
 
 /* One iteration of pathTrace's loop body (trace.h:413-527) for every queued path, minus the two
  * scene queries: the closest hit arrives in hits[], the shadow query leaves through the shadow queue. */
-__global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int bounce, int cur, unsigned first_sample)
+__global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n_max, int bounce, int cur, unsigned first_sample)
 {
+    unsigned n = rd.counters[2 * bounce];                        /* this bounce's queue size: never seen by the host */
+    n = n < n_max ? n : n_max;
+    if (blockIdx.x * blockDim.x >= n) return;                    /* the whole block: queue_push2 below needs all of a block's threads */
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     bool push_shadow = false, push_next = false;
@@ -460,7 +490,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
         p = rd.qpath[cur][i];
         const crt_ray ray = rd.rays[cur][i];
         const crt_hit hit = rd.hits[i];
-        const unsigned pixel = p % rd.npix, samp = first_sample + p / rd.npix;
+        const unsigned pixel = rd.pix_offset + p % rd.npix, samp = first_sample + p / rd.npix;
         V3 beta = v3p(rd.beta + 3 * (size_t)p);
         V3 L = v3p(rd.L + 3 * (size_t)p);
         unsigned good = rd.good[p] & 0x7FFFFFFFu;
@@ -480,7 +510,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                 }
             } else {
                 V3 env = v3(0.f, 0.f, 0.f);                       /* the reference leaves it uninitialised without an env light */
-                if (rd.has_env) env = scale(v3p(rd.env_color), rd.env_intensity);    /* getEnvLightIncRadiance CONSTANT, lights.cpp:233-238 */
+                if (rd.has_env) env = env_radiance(rd, env_transform(rd, v3p(ray.d)));   /* trace.h:436-441, lights.cpp:233-248 */
                 env = mul(env, beta);
                 L = add(L, env);
                 good++;
@@ -535,7 +565,20 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
             if (dp != 0.0f) tangent = normalize(sub(tangent, scale(normal, dp)));
             const V3 binormal = normalize(cross(normal, tangent));
             /* ---- computeScatteringFunc: MATTE, sigma 0 -> one Lambertian; MIRROR -> one SpecularReflection (materials.cpp:116-136) ---- */
-            const V3 cd = v3p(mat.color);
+            V3 cd = v3p(mat.color);
+            if (rd.mat_tex && rd.mat_tex[so.mat] >= 0 && (mat.type == CRT_MAT_MATTE || mat.type == CRT_MAT_PLASTIC)) {
+                /* Matte_getDiffuseColor / Plastic.diffuse (materials.cpp:51-60,:146-149) at the hit's texcoord: interpTexcoord + the
+                 * [0, 1] wrap of rayIntersectFlatTriangle / SmoothTriangle (triangle.cpp:191-198,:237-243); create() admits textured
+                 * materials on these two kinds only */
+                const size_t tri = (size_t)__float_as_int(so.type == CRT_SMOOTH_TRIANGLE ? so.p[0] : so.p[13]);
+                float uv[2], c[3];
+                sr_interp_uv(uv, hit.beta, hit.gamma, rd.vuv + 6 * tri);
+                sr_wrap_uv(uv);
+                const crt_texture t = rd.tex[rd.mat_tex[so.mat]];
+                crt_tex_color(c, t.width, t.height, t.comp, t.is_float, t.data, uv);
+                cd = v3p(c);
+                mat.color[0] = c[0]; mat.color[1] = c[1]; mat.color[2] = c[2];           /* the lobes below read kd from the material */
+            }
             const bool oren = mat.type == CRT_MAT_MATTE && mat.sigma != 0.0f;   /* BSDF_addOrenNayar; a, b sit in ior_in, ior_out of the device copy */
             const unsigned dim0 = DIM_BOUNCE0 + DIMS_PER_BOUNCE * (unsigned)bounce;
             #define RNG(d) crt_rng(rd.seed_lo, rd.seed_hi, pixel, samp, dim0 + (d))
@@ -583,15 +626,16 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
                     const V3 s2h = sub(sp, hp);
                     wi = normalize(s2h);
                     lpdf *= dot(s2h, s2h) / fabsf(dot(sn, neg(wi)));
-                } else {                                          /* ENVLIGHT, identity transform */
+                } else {                                          /* ENVLIGHT, trace.h:290-310 */
                     V3 h = sample_hemisphere(ls0, ls1);
                     h = ortho(tangent, binormal, normal, h);
+                    h = env_transform(rd, h);                     /* mat3_mult_vec3(h_sample, env_light->transform, h_copy) */
                     sp = add(hp, scale(h, rd.env_world_radius));
                     sn = neg(h);
                     wi = h;
                     lpdf = (float)((double)fabsf(dot(h, normal)) * RD_INV_PI);
                 }
-                const V3 Li = scale(v3p(lt.color), lt.intensity);
+                const V3 Li = lt.kind == LIGHT_ENV ? env_radiance(rd, wi) : scale(v3p(lt.color), lt.intensity);   /* trace.h:309 / :288 */
                 const V3 s2h = sub(sp, hp);
                 if (!(dot(s2h, sn) > 0.0f || dot(s2h, normal) < 0.0f) && lpdf > 0.0f && !is_black(Li)) {
                     V3 f = mat.type == CRT_MAT_PLASTIC ? fb_diffuse_f(wi, wo_sr, mat)             /* the DIFFUSE lobe of the two, on the WORLD vectors too */
@@ -678,7 +722,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
         rd.good[p] = good | (spec ? 0x80000000u : 0u);
     }
     unsigned ns, ss;
-    queue_push2((unsigned long long*)rd.counters, push_next, push_shadow, &ns, &ss);
+    queue_push2((unsigned long long*)(rd.counters + 2 * (bounce + 1)), push_next, push_shadow, &ns, &ss);
     if (push_shadow) {
         rd.srays[ss] = sray; rd.sdist[ss] = sdist; rd.spath[ss] = p;
         rd.scontrib[3 * (size_t)ss] = scontrib.x; rd.scontrib[3 * (size_t)ss + 1] = scontrib.y; rd.scontrib[3 * (size_t)ss + 2] = scontrib.z;
@@ -688,8 +732,10 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n, int 
 
 /* tail of estimateDirect / pathTrace's direct-light step: `if(!in_shadow)` (trace.h:348-355), then
  * L += contrib and good_paths++ when contrib is not black (trace.h:475-477) */
-__global__ __launch_bounds__(256) void k_pt_accumulate(RenderDev rd, unsigned n)
+__global__ __launch_bounds__(256) void k_pt_accumulate(RenderDev rd, unsigned n_max, int bounce)
 {
+    unsigned n = rd.counters[2 * (bounce + 1) + 1];              /* shadow rays queued by this bounce */
+    n = n < n_max ? n : n_max;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (rd.socc[i]) return;
@@ -731,6 +777,10 @@ struct crt_renderer {
     crt_render_stats stats;
     hipStream_t stream;
     std::vector<void*> allocs;
+    /* the host follows the device two bounces behind: the queue sizes of each bounce land here (page-locked) */
+    uint32_t* h_counts; size_t counts_words;
+    std::vector<hipEvent_t> ev_count;                 /* ring of 4: bounce b's sizes have arrived */
+    std::vector<hipEvent_t> ev_time;                  /* 4 per bounce launched in a pass: extend start / stop, shadow start / stop */
 };
 
 namespace {
@@ -770,6 +820,9 @@ void crt_renderer_destroy(crt_renderer* r)
     DevGuard g(r->device);
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
     for (void* p : r->allocs) (void)hipFree(p);
+    for (hipEvent_t e : r->ev_count) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->ev_time) (void)hipEventDestroy(e);
+    if (r->h_counts) (void)hipHostFree(r->h_counts);
     delete r;
 }
 
@@ -790,6 +843,24 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT &&
             mt.type != CRT_MAT_PLASTIC && mt.type != CRT_MAT_GLASS && mt.type != CRT_MAT_METAL) return CRT_E_UNSUPPORTED;
     }
+    if (d->num_textures < 0 || (d->num_textures > 0 && !d->textures)) return CRT_E_INVALID;
+    for (int k = 0; k < d->num_textures; k++) {
+        const crt_texture& t = d->textures[k];
+        if (t.width < 1 || t.height < 1 || t.comp < 3 || t.comp > 4 || !t.data) return CRT_E_INVALID;    /* getTexColor reads three channels */
+        if ((unsigned long long)t.width * (unsigned long long)t.height > (1ull << 28)) return CRT_E_TOOBIG;
+    }
+    if (d->env_map < 0 || d->env_map > d->num_textures) return CRT_E_INVALID;
+    if (d->env_map && !d->has_env_light) return CRT_E_INVALID;
+    bool any_tex = false;
+    if (d->material_diffuse_tex)
+        for (int m = 0; m < d->num_materials; m++) {
+            const int ti = d->material_diffuse_tex[m];
+            if (ti < -1 || ti >= d->num_textures) return CRT_E_INVALID;
+            if (ti >= 0) any_tex = true;
+        }
+    int row_begin = d->row_begin, row_end = d->row_end;
+    if (row_begin == 0 && row_end == 0) row_end = film->frame_res_height;
+    if (row_begin < 0 || row_end <= row_begin || row_end > film->frame_res_height) return CRT_E_INVALID;
     std::vector<ShadeObj> objs((size_t)in->num_obj);
     std::vector<LightRec> lights;
     const crt_mesh_shading* ms = d->mesh_shading;
@@ -800,7 +871,10 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         l.kind = LIGHT_ENV; l.obj_type = -1;
         memcpy(l.color, d->env_color, sizeof l.color);
         l.intensity = d->env_intensity;
-        l.power = (d->env_color[0] + d->env_color[1] + d->env_color[2]) / 3.0f;            /* buildscene.h:894-895 */
+        /* buildscene.h:894-895 averages EnvLight.color -- which the TEXTURE branch of the parser never sets (:479-483, malloc'd
+         * memory); WHITE is taken there, as the parser's own fallback does (:486-487) */
+        if (d->env_map) { l.color[0] = l.color[1] = l.color[2] = 1.0f; }
+        l.power = (l.color[0] + l.color[1] + l.color[2]) / 3.0f;
         l.power *= d->env_intensity * d->env_world_radius;
         lights.push_back(l);
     }
@@ -812,6 +886,10 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         const crt_material& mt = d->materials[mi];
         ShadeObj so; memset(&so, 0, sizeof so);
         so.type = type; so.mat = mi;
+        if (any_tex && d->material_diffuse_tex[mi] >= 0 && (mt.type == CRT_MAT_MATTE || mt.type == CRT_MAT_PLASTIC)) {
+            /* a texture needs a texcoord the reference defines: the mesh triangle kinds (triangle.cpp:191-198,:237-243) */
+            if ((type != CRT_FLAT_TRIANGLE && type != CRT_SMOOTH_TRIANGLE) || !ms || !ms->vertex_uv) return CRT_E_UNSUPPORTED;
+        }
         /* EMISSIVE mesh triangles: initMeshLights (buildscene.h:749-833) registers them as MeshLights, which preprocessLights
          * gives no power (no MESHLIGHT case, buildscene.h:879-917) and estimateDirect cannot sample ("Invalid light type",
          * trace.h:311-313).  For pathTrace they are surfaces that emit when a camera ray or a specular / glossy bounce finds them;
@@ -832,6 +910,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
             host_normalize(so.p, c);                              /* calcTriangleNormal, triangle.cpp:4-12 */
             if (type == CRT_FLAT_TRIANGLE && ms && ms->flat_normal) memcpy(so.p, ms->flat_normal + 3 * (size_t)ref, 12);   /* FlatTriangle.normal */
             host_normalize(so.p + 3, e1);                         /* dpdu: the reference leaves it unset for these two types; see DESIGN.md "N1" */
+            memcpy(so.p + 13, &ref, 4);                           /* triangle index: texcoords of a textured FLAT_TRIANGLE */
         } else if (type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) {
             if (ref < 0 || ref >= in->num_shapes || !in->shapes || in->shapes[ref].type != type) return CRT_E_INVALID;
             const float* sp = in->shapes[ref].p;
@@ -882,10 +961,11 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     crt_renderer* r = new (std::nothrow) crt_renderer();
     if (!r) return CRT_E_NOMEM;
     r->scene = scene; r->device = device; r->samples = 0; r->stream = 0;
+    r->h_counts = 0; r->counts_words = 0;
     memset(&r->stats, 0, sizeof r->stats);
     memset(&r->rd, 0, sizeof r->rd);
     DevGuard g(device);
-    const uint32_t npix = (uint32_t)npix64;
+    const uint32_t npix = (uint32_t)(row_end - row_begin) * (uint32_t)film->frame_res_width;     /* the band this renderer renders */
     uint32_t spp = d->samples_in_flight;
     if (spp == 0) { spp = (uint32_t)((1u << 25) / npix); if (spp < 1) spp = 1; }    /* ~32 M paths per pass (150 bytes of state each): the
                                                                                      walk kernels' tails shrink with the batch, 22.2 -> 25.0 samples/s/pixel at 4K */
@@ -929,7 +1009,15 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.spath, P);
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.scontrib, 3 * P);
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.socc, P);
-    if (rc == CRT_OK) rc = dev_alloc(r, &rd.counters, (size_t)64);
+    if (d->max_depth > (1 << 20)) { crt_renderer_destroy(r); return CRT_E_TOOBIG; }      /* two queue-size words per bounce, device and host */
+    r->counts_words = 2 * ((size_t)d->max_depth + 2);
+    if (r->counts_words < 64) r->counts_words = 64;
+    if (rc == CRT_OK) rc = dev_alloc(r, &rd.counters, r->counts_words);
+    if (rc == CRT_OK && hipHostMalloc((void**)&r->h_counts, r->counts_words * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { r->h_counts = 0; rc = CRT_E_NOMEM; }
+    for (int k = 0; k < 4 && rc == CRT_OK; k++) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = CRT_E_HIP; else r->ev_count.push_back(e);
+    }
     if (rc == CRT_OK) rc = dev_alloc(r, &rd.color, 3 * (size_t)npix);
     bool ok = rc == CRT_OK;
     ok = ok && hipMemcpy(d_objs, objs.data(), objs.size() * sizeof(ShadeObj), hipMemcpyHostToDevice) == hipSuccess;
@@ -961,8 +1049,28 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         ok = ok && hipMemcpy(d_vt, ms->vertex_tangents, 9 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(d_nm, ms->normal_mats, 9 * (size_t)ms->num_normal_mats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     }
+    /* textures: texel arrays copied as they are, Texture records with device pointers; texcoords of the mesh triangles */
+    crt_texture* d_tex = 0; int32_t* d_mat_tex = 0; float* d_vuv = 0;
+    if (ok && d->num_textures > 0 && (any_tex || d->env_map)) {
+        std::vector<crt_texture> tex(d->textures, d->textures + d->num_textures);
+        for (crt_texture& t : tex) {
+            const size_t bytes = (size_t)t.width * (size_t)t.height * (size_t)t.comp * (t.is_float ? sizeof(float) : 1);
+            unsigned char* dp = 0;
+            ok = ok && dev_alloc(r, &dp, bytes) == CRT_OK;
+            ok = ok && hipMemcpy(dp, t.data, bytes, hipMemcpyHostToDevice) == hipSuccess;
+            t.data = dp;
+        }
+        ok = ok && dev_alloc(r, &d_tex, tex.size()) == CRT_OK;
+        ok = ok && hipMemcpy(d_tex, tex.data(), tex.size() * sizeof(crt_texture), hipMemcpyHostToDevice) == hipSuccess;
+        if (any_tex) {
+            ok = ok && dev_alloc(r, &d_mat_tex, (size_t)d->num_materials) == CRT_OK;
+            ok = ok && hipMemcpy(d_mat_tex, d->material_diffuse_tex, (size_t)d->num_materials * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+            ok = ok && dev_alloc(r, &d_vuv, 6 * (size_t)in->num_tris) == CRT_OK;
+            ok = ok && hipMemcpy(d_vuv, ms->vertex_uv, 6 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        }
+    }
     ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;
-    ok = ok && hipMemset(rd.counters, 0, 256) == hipSuccess;
+    ok = ok && hipMemset(rd.counters, 0, r->counts_words * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipStreamCreate(&r->stream) == hipSuccess;
     if (!ok) { crt_renderer_destroy(r); return rc != CRT_OK ? rc : CRT_E_HIP; }
     rd.objs = d_objs; rd.mats = d_mats; rd.lights = d_lights;
@@ -970,6 +1078,14 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     rd.shapes = d_shapes; rd.num_shapes = any_generic ? in->num_shapes : 0;
     rd.num_lights = (int32_t)lights.size();
     rd.has_env = d->has_env_light ? 1 : 0;
+    rd.tex = d_tex; rd.mat_tex = d_mat_tex; rd.vuv = d_vuv;
+    rd.env_map = d->env_map;
+    {
+        bool zero = true;
+        for (int k = 0; k < 9; k++) if (d->env_transform[k] != 0.0f) zero = false;
+        for (int k = 0; k < 9; k++) rd.env_xf[k] = zero ? ((k % 4 == 0) ? 1.0f : 0.0f) : d->env_transform[k];
+    }
+    rd.pix_offset = (uint32_t)row_begin * (uint32_t)film->frame_res_width;
     rd.max_depth = d->max_depth;
     memcpy(rd.env_color, d->env_color, sizeof rd.env_color);
     rd.env_intensity = d->env_intensity; rd.env_world_radius = d->env_world_radius;
@@ -992,32 +1108,51 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
         const uint32_t spp = num_samples - done < r->spp_max ? num_samples - done : r->spp_max;
         const uint32_t first_sample = (uint32_t)r->samples;
         const unsigned P = spp * rd.npix;
+        /* The queue sizes never leave the device on the critical path: every launch of a bounce reads its ray count from
+         * rd.counters (counted launches, sized for P).  The host only FOLLOWS, two bounces behind, through an 8-byte copy
+         * into page-locked memory per bounce, to stop launching once the paths have died out (Russian roulette, misses)
+         * -- so the GPU always has the next bounce queued and never waits for the host. */
+        if (hipMemsetAsync(rd.counters, 0, r->counts_words * sizeof(uint32_t), st) != hipSuccess) return CRT_E_HIP;
         hipLaunchKernelGGL(k_pt_generate, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, first_sample);
-        unsigned n = P; int cur = 0;
-        for (int bounce = 0; bounce <= rd.max_depth && n > 0; bounce++) {
-            int rc = crt_intersect_batch_dev(r->scene, rd.rays[cur], n, rd.hits, st);
-            if (rc != CRT_OK) return rc;
-            float ms = 0.f;
-            if (crt_scene_last_kernel_ms(r->scene, &ms) == CRT_OK) r->stats.ms_extend += ms;
-            r->stats.rays_closest += n;
-            if (hipMemsetAsync(rd.counters, 0, 8, st) != hipSuccess) return CRT_E_HIP;
-            hipLaunchKernelGGL(k_pt_shade, dim3((n + 255) / 256), dim3(256), 0, st, rd, n, bounce, cur, first_sample);
-            uint32_t cnt[2] = { 0, 0 };
-            if (hipMemcpyAsync(cnt, rd.counters, sizeof cnt, hipMemcpyDeviceToHost, st) != hipSuccess) return CRT_E_HIP;
-            if (hipStreamSynchronize(st) != hipSuccess) return CRT_E_HIP;
-            if (cnt[0] > P || cnt[1] > P) return CRT_E_HIP;       /* cannot happen: one push of each kind per path */
-            if (cnt[1] > 0) {
-                rc = crt_shadow_batch_dev(r->scene, rd.srays, rd.sdist, cnt[1], 0, rd.socc, st);
-                if (rc != CRT_OK) return rc;
-                if (crt_scene_last_kernel_ms(r->scene, &ms) == CRT_OK) r->stats.ms_shadow += ms;
-                r->stats.rays_shadow += cnt[1];
-                hipLaunchKernelGGL(k_pt_accumulate, dim3((cnt[1] + 255) / 256), dim3(256), 0, st, rd, cnt[1]);
+        int cur = 0, launched = 0;
+        for (int bounce = 0; bounce <= rd.max_depth; bounce++) {
+            if (bounce >= 2) {
+                if (hipEventSynchronize(r->ev_count[(bounce - 2) & 3]) != hipSuccess) return CRT_E_HIP;
+                if (r->h_counts[2 * (bounce - 1)] == 0) break;                /* bounce - 2 queued nothing: the pass is over */
             }
-            n = cnt[0]; cur ^= 1;
+            while (r->ev_time.size() < 4 * (size_t)(bounce + 1)) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return CRT_E_HIP;
+                r->ev_time.push_back(e);
+            }
+            hipEvent_t* ev = &r->ev_time[4 * (size_t)bounce];
+            if (hipEventRecord(ev[0], st) != hipSuccess) return CRT_E_HIP;
+            int rc = crt_intersect_batch_dev_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, P, rd.hits, st);
+            if (rc != CRT_OK) return rc;
+            if (hipEventRecord(ev[1], st) != hipSuccess) return CRT_E_HIP;
+            hipLaunchKernelGGL(k_pt_shade, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, bounce, cur, first_sample);
+            if (hipMemcpyAsync(r->h_counts + 2 * (bounce + 1), rd.counters + 2 * (bounce + 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess) return CRT_E_HIP;
+            if (hipEventRecord(r->ev_count[bounce & 3], st) != hipSuccess) return CRT_E_HIP;
+            if (hipEventRecord(ev[2], st) != hipSuccess) return CRT_E_HIP;
+            rc = crt_shadow_batch_dev_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, P, 0, rd.socc, st);
+            if (rc != CRT_OK) return rc;
+            if (hipEventRecord(ev[3], st) != hipSuccess) return CRT_E_HIP;
+            hipLaunchKernelGGL(k_pt_accumulate, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, bounce);
+            cur ^= 1; launched++;
         }
         hipLaunchKernelGGL(k_pt_finish, dim3((rd.npix + 255) / 256), dim3(256), 0, st, rd, spp, first_sample);
         if (hipGetLastError() != hipSuccess) return CRT_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return CRT_E_HIP;
+        r->h_counts[0] = P;
+        for (int b = 0; b < launched; b++) {
+            const uint32_t n_ext = r->h_counts[2 * b], n_sh = r->h_counts[2 * (b + 1) + 1];
+            if (n_ext > P || n_sh > P) return CRT_E_HIP;          /* cannot happen: one push of each kind per path */
+            r->stats.rays_closest += n_ext;
+            r->stats.rays_shadow += n_sh;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r->ev_time[4 * (size_t)b], r->ev_time[4 * (size_t)b + 1]) == hipSuccess) r->stats.ms_extend += ms;
+            if (hipEventElapsedTime(&ms, r->ev_time[4 * (size_t)b + 2], r->ev_time[4 * (size_t)b + 3]) == hipSuccess) r->stats.ms_shadow += ms;
+        }
         r->samples += spp; done += spp;
     }
     r->stats.samples = r->samples;

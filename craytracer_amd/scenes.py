@@ -651,3 +651,78 @@ def shadow_rays_toward(points, lo, hi, seed=11):
     dist[dist == 0] = 1
     d /= dist[:, None]
     return np.concatenate([points, d], 1).astype(F32), dist.astype(F32)
+
+
+def procedural_texture(width, height, seed=1, is_float=False):
+    """A seeded RGB texture: coloured checker with noise (uint8), or a sky with a bright lobe for an environment map
+    (float32 texels in the 0..255-and-above range getTexColor divides by 255, as the reference's EXR maps are read)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    if not is_float:
+        check = (((x * 8) // width + (y * 8) // height) % 2).astype(np.float32)
+        base = np.stack([0.25 + 0.7 * check, 0.3 + 0.5 * (x / width), 0.9 - 0.6 * check], -1)
+        img = np.clip(base * 255.0 + rng.integers(-20, 21, (height, width, 3)), 0, 255).astype(np.uint8)
+        return np.ascontiguousarray(img)
+    v = y / max(height - 1, 1)
+    sky = np.stack([90 + 100 * (1 - v), 130 + 90 * (1 - v), 200 + 55 * (1 - v)], -1)
+    sun = np.exp(-(((x - 0.3 * width) / (0.04 * width)) ** 2 + ((y - 0.25 * height) / (0.06 * height)) ** 2))
+    img = sky + 6000.0 * sun[..., None] * np.array([1.0, 0.9, 0.7])
+    return np.ascontiguousarray(img.astype(np.float32))
+
+
+def textured_scene(n_lat=24, n_lon=48, max_depth=4, rng_seed=5, seed=13, tex_size=64, env_size=(128, 64), env_intensity=1.0,
+                   samples_in_flight=0, rows=None):
+    """Stand-in for BASELINE.json configs[3] (textured meshes + environment map): an open floor of TRIANGLE objects, one
+    SMOOTH_TRIANGLE blob with a textured MATTE material and one FLAT_TRIANGLE blob with a textured PLASTIC material (texcoords
+    running past 1 so the wrap is exercised), lit by a lat-long float environment map behind EnvLight.transform =
+    mat3_rotate_y(-0.76) (buildscene.h:515) and a small sphere light.  Returns (SceneInput, RenderDesc, pos, look)."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0.08, math.pi - 0.08, n_lat + 1, dtype=np.float64)
+    ph = np.linspace(0.0, 2.0 * math.pi, n_lon, endpoint=False, dtype=np.float64)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    rad = 1.0 + 0.2 * np.sin(2 * T) * np.cos(3 * P) + 0.03 * rng.standard_normal(T.shape)
+    pos = np.stack([rad * np.sin(T) * np.cos(P), rad * np.cos(T), rad * np.sin(T) * np.sin(P)], -1).reshape(-1, 3).astype(F32)
+    nrm = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    tan = np.stack([-np.sin(P), np.zeros_like(P), np.cos(P)], -1).reshape(-1, 3).astype(F32)
+    uv = np.stack([2.5 * P / (2.0 * math.pi) - 0.25, 1.5 * T / math.pi], -1).reshape(-1, 2).astype(F32)     # beyond [0, 1] on purpose
+    idx = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d = a + n_lon, b + n_lon
+            idx += [a, c, b, b, c, d]
+    idx = np.asarray(idx, np.int32)
+    tri_uv = uv[idx].reshape(-1, 6)
+    b1 = api.bake_mesh(pos, idx, scaling=(0.3, 0.35, 0.3), orientation=(10.0, 30.0, -5.0), location=(-0.45, 0.36, 0.0),
+                       normals=np.asarray(nrm, F32), tangents=tan)
+    b2 = api.bake_mesh(pos, idx, scaling=(0.28, 0.25, 0.3), orientation=(0.0, -40.0, 15.0), location=(0.45, 0.27, 0.1),
+                       normals=np.asarray(nrm, F32), tangents=tan)
+    s = 3.0
+    floor = np.array([[[-s, 0, -s], [s, 0, -s], [s, 0, s]], [[-s, 0, -s], [s, 0, s], [-s, 0, s]]], F32).reshape(2, 9)
+    nw, n1, n2 = len(floor), len(b1["tri_verts"]), len(b2["tri_verts"])
+    tris = np.concatenate([floor, b1["tri_verts"], b2["tri_verts"]], 0)
+    sl = ShapeList()
+    sl.sphere((0.0, 1.6, 0.9), 0.08)
+    shapes = np.array(sl.shapes, api.SHAPE_DTYPE)
+    obj_type = np.concatenate([np.full(nw, api.TRIANGLE), np.full(n1, api.SMOOTH_TRIANGLE), np.full(n2, api.FLAT_TRIANGLE), [api.SPHERE]]).astype(np.int32)
+    obj_ref = np.concatenate([np.arange(nw + n1 + n2), [0]]).astype(np.int32)
+    si = api.SceneInput(tris, shapes, obj_type, obj_ref)
+    pad3, pad9, pad6 = np.zeros((nw, 3), F32), np.zeros((nw, 9), F32), np.zeros((nw, 6), F32)
+    ms = api.MeshShading(flat_normal=np.concatenate([pad3, b1["flat_normal"], b2["flat_normal"]], 0),
+                         vertex_normals=np.concatenate([pad9, b1["vertex_normals"], b2["vertex_normals"]], 0),
+                         vertex_tangents=np.concatenate([pad9, b1["vertex_tangents"], b2["vertex_tangents"]], 0),
+                         normal_mat_index=np.concatenate([np.zeros(nw + n1, np.int32), np.ones(n2, np.int32)]),
+                         normal_mats=np.stack([b1["normal_mat"].reshape(9), b2["normal_mat"].reshape(9)]),
+                         vertex_uv=np.concatenate([pad6, tri_uv, tri_uv], 0))
+    mats = np.array([api.material(api.MAT_MATTE, (0.55, 0.55, 0.5)), api.material(api.MAT_MATTE, (1.0, 1.0, 1.0)),
+                     api.material(api.MAT_PLASTIC, (1.0, 1.0, 1.0), ks=(0.25, 0.25, 0.25), uroughness=0.15),
+                     api.material(api.MAT_EMISSIVE, (1.0, 0.95, 0.9), 40.0)], api.MATERIAL_DTYPE)
+    mat_of = [0] * nw + [1] * n1 + [2] * n2 + [3]
+    textures = [procedural_texture(tex_size, tex_size, seed=seed), procedural_texture(tex_size // 2, tex_size, seed=seed + 1),
+                procedural_texture(env_size[0], env_size[1], seed=seed + 2, is_float=True)]
+    st, ct = np.float32(math.sin(np.float32(-0.76))), np.float32(math.cos(np.float32(-0.76)))      # mat3_rotate_y, util/mat.h:229-238
+    xf = np.array([[ct, 0, st], [0, 1, 0], [-st, 0, ct]], F32)
+    desc = api.RenderDesc(si, mat_of, mats, max_depth, seed=rng_seed, env=((1.0, 1.0, 1.0), env_intensity, 6.0), mesh_shading=ms,
+                          textures=textures, material_diffuse_tex=[-1, 0, 1, -1], env_map=2, env_transform=xf,
+                          samples_in_flight=samples_in_flight, rows=rows)
+    return si, desc, (0.0, 0.9, 2.6), (0.0, 0.35, 0.0)

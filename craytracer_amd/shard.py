@@ -66,3 +66,46 @@ def render_sharded(renderer, spp_per_rank, rank, world, device=None):
         buf = torch.from_numpy(host.reshape(-1).copy())
     buf, total = combine_radiance(buf, spp_per_rank)
     return buf, total
+
+
+def tile_rows(height, rank, world):
+    """Tile sharding: the image rows [begin, end) rank `rank` renders -- a contiguous band; bands of
+    all ranks cover the frame once.  Pass as RenderDesc(rows=...)."""
+    return shard_range(height, rank, world)
+
+
+def gather_tiles(band, height, width, rank, world):
+    """All-gather of the per-rank bands into the whole frame (every rank gets it): `band` is this rank's colour buffer,
+    a float32 tensor of tile_rows(height, rank, world) rows x width x 3 (on the GPU with the nccl backend = RCCL all-gather over
+    xGMI, 12.4 MB per GPU at 4K on 8 GPUs; on the host with gloo).  Bands differ in size by at most one row, so they are padded
+    to the largest for the collective and cut back after it.  Returns [height, width, 3]."""
+    b, e = tile_rows(height, rank, world)
+    band = band.reshape(e - b, width, 3)
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return band.clone()
+    rows_max = -(-height // world)
+    mine = torch.zeros((rows_max, width, 3), dtype=band.dtype, device=band.device)
+    mine[: e - b] = band
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = []
+    for r in range(world):
+        rb, re = tile_rows(height, r, world)
+        out.append(parts[r][: re - rb])
+    return torch.cat(out, 0)
+
+
+def render_tiled(renderer, spp, height, width, rank, world, device=None):
+    """Tile sharding of a render: `renderer` was created with rows=tile_rows(height, rank, world); every rank renders `spp`
+    samples of its band, then the bands are all-gathered.  Because pixel indices (camera rays, random numbers) are those of the
+    whole frame, the result equals a single renderer's whole frame bit for bit."""
+    renderer.reset(0)
+    renderer.render(spp)
+    if device is not None and torch.device(device).type == "cuda" and (not dist.is_initialized() or dist.get_backend() == "nccl"):
+        band = torch.zeros(renderer.width * renderer.height * 3, dtype=torch.float32, device=device)
+        renderer.read_dev(band.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+    else:
+        host, _ = renderer.read()
+        band = torch.from_numpy(host.reshape(-1).copy())
+    return gather_tiles(band, height, width, rank, world)

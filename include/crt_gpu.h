@@ -245,6 +245,15 @@ int  crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_
 int  crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                           float* d_t_out, uint8_t* d_occluded_out, void* stream);
 
+/* Counted launches.  No counterpart in the reference (its callers know how many rays they hold): for wavefront drivers whose
+ * queue sizes live on the device.  The kernels read the ray count from *d_n (a device word that must be final when the launch
+ * reaches it in stream order; values above n_max are clamped to n_max, which also sizes the launch) -- otherwise exactly
+ * crt_intersect_batch_dev / crt_shadow_batch_dev.  crt_renderer_render chains its bounces through these, so the host does
+ * not wait for the GPU between bounces. */
+int  crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const uint32_t* d_n, size_t n_max, crt_hit* d_hits, void* stream);
+int  crt_shadow_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, const uint32_t* d_n, size_t n_max,
+                                  float* d_t_out, uint8_t* d_occluded_out, void* stream);
+
 /* crt_intersect_batch_dev for callers that cannot allocate.  No counterpart in the reference: it exists for
  * callers that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid
  * allocation.  Same kernels, same results bit for bit; the device memory they need beyond d_rays / d_hits (queue
@@ -341,6 +350,12 @@ typedef struct crt_mesh_shading {
                                             (a mesh without texcoords: the reference interpolates nothing, triangle.cpp:191-194) */
 } crt_mesh_shading;
 
+/* Texture (texture.h:5-13): width x height texels of `comp` channels, rows top to bottom as stb_image / readRgba1 leave
+ * them; data = unsigned char [h][w][comp], or float [h][w][comp] when is_float (the EXR environment maps,
+ * buildscene.h:479-483).  getTexColor (texture.cpp:27-86) reads the NEAREST texel (its mirrored wrap and its rounding as
+ * written) and divides by 255 -- float texels too. */
+typedef struct crt_texture { int32_t width, height, comp, is_float; const void* data; } crt_texture;
+
 typedef struct crt_render_desc {
     const crt_scene_input* objects;      /* the insertion-order arrays the scene was built from */
     const int32_t*      obj_material;    /* [num_obj] index into materials[] (getObjectMatPtr, shapes.cpp) */
@@ -354,6 +369,18 @@ typedef struct crt_render_desc {
     uint32_t            samples_in_flight;/* samples per pixel traced concurrently; 0 = library picks (~2^25 paths, 150 bytes each) */
     uint64_t            seed;
     const crt_mesh_shading* mesh_shading;/* NULL: no FLAT normals given, SMOOTH_TRIANGLE objects refused */
+    /* textures (all optional; zero-filled = none) */
+    const crt_texture*  textures;
+    int32_t             num_textures;
+    const int32_t*      material_diffuse_tex; /* [num_materials] index into textures[] or -1: Matte.diffuse / Plastic.diffuse
+                                                 (materials.cpp:51-60,:146-149); honoured on FLAT_TRIANGLE / SMOOTH_TRIANGLE objects with
+                                                 mesh_shading->vertex_uv, anything else with a textured material is refused */
+    int32_t             env_map;         /* 1 + index into textures[] of EnvLight.env_map (type TEXTURE, lights.cpp:238-247); 0 = type CONSTANT */
+    float               env_transform[9];/* EnvLight.transform, row-major (buildscene.h:515: mat3_rotate_y(-0.76) for a map); all zero = identity */
+    /* the part of the frame this renderer renders: image rows [row_begin, row_end), 0 / 0 = all.  The colour buffer then holds
+     * those rows only; pixel indices (camera rays, random numbers) stay those of the whole frame, so bands rendered apart are
+     * bit for bit the rows of the whole frame (tile sharding: one band per GPU, all-gather). */
+    int32_t             row_begin, row_end;
 } crt_render_desc;
 
 typedef struct crt_render_stats {

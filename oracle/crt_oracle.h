@@ -90,6 +90,10 @@ float oracle_trace_material_bsdf(const crt_material* mat, float rand_float, cons
 void  oracle_trace_beckmann(float alphax, float alphay, const float* wo, const float* wi, const float* wh, const float* sample, float* out);
 void  oracle_trace_fresnel_conductor(const float* normal, const float* wo, const float* etaT, const float* etaI, const float* k, float* out);
 float oracle_trace_roughness_to_alpha(float roughness);
+/* getTexColor (texture.cpp:27-86; parity unpinned, the file needs stb_image.h) and the lat-long mapping of getEnvLightIncRadiance
+ * (util/math.h:95-107; pinned against oracle/_ref) */
+void  oracle_trace_tex_color(const crt_texture* tex, const float* uv, float* out);
+void  oracle_trace_env_uv(const float* dir, float* uv);
 
 #ifdef __cplusplus
 }

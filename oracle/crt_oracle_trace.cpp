@@ -136,6 +136,8 @@ struct BxDF {                  /* the union of reflection.h's lobe structs */
 };
 struct ShadeRec {              /* util/shaderec.h, the fields this form reads */
     vec3 hit_point, normal, wo, dpdu;
+    vec2 uv; bool has_uv;      /* written for FLAT / SMOOTH mesh triangles with texcoords (triangle.cpp:191-198,:237-243) */
+    int mat_index;
     const crt_material* mat;
     /* BSDF (reflection.h:157-165) */
     vec3 b_normal, b_tangent, b_binormal;
@@ -369,6 +371,99 @@ void intersectShapeRecord(const crt_scene_input* in, const crt_shape& sh, const 
 }
 
 /* ShadeRec tail of the intersector that produced `hit` */
+/* getTexColor, texture.cpp:27-86: nearest texel, mirrored about 0, reflected beyond 1, v flipped; both kinds of texel
+ * are divided by 255.  PARITY UNPINNED: texture.cpp includes stb_image.h, which the reference does not ship. */
+bool getTexColor(vec3 color_out, const crt_texture* texture, const vec2 texcoord)
+{
+    float u_float = texcoord[0];
+    if (u_float < 0.0f) u_float = -u_float;
+    if (u_float > 1.0f) {
+        u_float = u_float - (int)u_float;
+        u_float = 1.0f - u_float;
+    }
+    u_float = u_float * texture->width;
+    int u;
+    if (u_float - (int)u_float > 0.5f) u = (int)u_float + 1;
+    else u = (int)u_float;
+    u = u % texture->width;
+
+    float v_float = texcoord[1];
+    if (v_float < 0.0f) v_float = -v_float;
+    if (v_float > 1.0f) {
+        v_float = v_float - (int)v_float;
+        v_float = 1.0f - v_float;
+    }
+    v_float = 1.0f - v_float;
+    v_float = v_float * texture->height;
+    int v;
+    if (v_float - (int)v_float > 0.5f) v = (int)v_float + 1;
+    else v = (int)v_float;
+    v = v % texture->height;
+
+    if (texture->is_float) {
+        const size_t row_len = (size_t)texture->width * texture->comp * sizeof(float);
+        const float* texel_ptr = (const float*)((const unsigned char*)texture->data + v * row_len + (size_t)u * texture->comp * sizeof(float));
+        vec3_assign(color_out, texel_ptr[0] / 255.0f, texel_ptr[1] / 255.0f, texel_ptr[2] / 255.0f);
+    } else {
+        const size_t row_len = (size_t)texture->width * texture->comp;
+        const unsigned char* texel_ptr = (const unsigned char*)texture->data + v * row_len + (size_t)u * texture->comp;
+        vec3_assign(color_out, texel_ptr[0] / 255.0f, texel_ptr[1] / 255.0f, texel_ptr[2] / 255.0f);
+    }
+    return true;
+}
+/* cartesianToSpherical + sphericalToUV, util/math.h:95-107.  PI there is a double (util/vec.h:6), so `out[0] += PI` and the two
+ * quotients are double arithmetic rounded when stored.  atan2f / acosf are taken as the double function rounded once (shared with
+ * the product: what host and device agree on); pinned against util/math.h through oracle/_ref to that allowance. */
+void envDirToUV(vec2 uv, const vec3 in)
+{
+    const double PI_D = 3.14159265358979323846264338327950288;
+    vec2 spherical;
+    spherical[0] = (float)atan2((double)in[2], (double)in[0]);
+    spherical[0] = (float)((double)spherical[0] + PI_D);
+    const float y = in[1] < -1.0f ? -1.0f : (in[1] > 1.0f ? 1.0f : in[1]);
+    spherical[1] = (float)acos((double)y);
+    uv[0] = (float)((double)spherical[0] / (2.0f * PI_D));
+    uv[1] = (float)(1.0f - (double)spherical[1] / PI_D);
+}
+/* getEnvLightIncRadiance, lights.cpp:233-248 */
+void getEnvLightIncRadiance(const Setup& S, vec3 r, const vec3 dir)
+{
+    const crt_render_desc* d = S.d;
+    if (d->env_map == 0) { vec3_scale(r, d->env_color, d->env_intensity); return; }
+    vec2 uv;
+    envDirToUV(uv, dir);
+    vec3 tex_color;
+    getTexColor(tex_color, &d->textures[d->env_map - 1], uv);
+    vec3_scale(r, tex_color, d->env_intensity);
+}
+/* mat3_mult_vec3(out, env_light->transform, v); an all-zero env_transform stands for the identity */
+void envTransform(const Setup& S, vec3 out, const vec3 v)
+{
+    const float* m = S.d->env_transform;
+    bool zero = true;
+    for (int k = 0; k < 9; k++) if (m[k] != 0.0f) zero = false;
+    const float id[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    if (zero) m = id;
+    vec3 t = { vec3_dot(m, v), vec3_dot(m + 3, v), vec3_dot(m + 6, v) };
+    vec3_copy(out, t);
+}
+/* interpTexcoord, triangle.cpp:170-183, and the wrap loops of :195-198 / :240-243 */
+void interpTexcoordWrapped(vec2 uv_out, float beta, float gamma, const float* t)
+{
+    const float w = 1.0f - beta - gamma;
+    float u = t[0] * w, v = t[1] * w;
+    u = u + t[2] * beta; v = v + t[3] * beta;
+    u = u + t[4] * gamma; v = v + t[5] * gamma;
+    uv_out[0] = u; uv_out[1] = v;
+    for (int k = 0; k < 2; k++) {
+        float x = uv_out[k];
+        if (!(x == x) || x > 1.0e6f || x < -1.0e6f) continue;     /* the reference's loops would spin */
+        while (x > 1.0f) x -= 1.0f;
+        while (x < 0.0f) x += 1.0f;
+        uv_out[k] = x;
+    }
+}
+
 void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hit& hit)
 {
     const crt_scene_input* in = S.d->objects;
@@ -379,6 +474,12 @@ void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hi
     vec3_add(sr->hit_point, ray.o, disp);                          /* getPointOnRay */
     vec3_negate(sr->wo, ray.d);
     sr->mat = S.d->obj_material ? &S.d->materials[S.d->obj_material[hit.obj]] : 0;
+    sr->mat_index = S.d->obj_material ? S.d->obj_material[hit.obj] : -1;
+    sr->has_uv = false; sr->uv[0] = sr->uv[1] = 0.0f;
+    if ((type == CRT_FLAT_TRIANGLE || type == CRT_SMOOTH_TRIANGLE) && S.d->mesh_shading && S.d->mesh_shading->vertex_uv) {
+        interpTexcoordWrapped(sr->uv, hit.beta, hit.gamma, S.d->mesh_shading->vertex_uv + 6 * (size_t)ref);
+        sr->has_uv = true;
+    }
     if (type == CRT_TRIANGLE) {
         vec3_copy(sr->normal, &S.tri_normal[3 * (size_t)ref]);
         if (vec3_dot(sr->wo, sr->normal) < 0.0f) vec3_negate(sr->normal, sr->normal);
@@ -947,12 +1048,20 @@ float BSDF_sample_f(vec3 f, vec3 wi, int* sampled_flags, const vec3 wo, const ve
 }
 
 /* computeScatteringFunc, materials.cpp:111-188, without textures */
-void computeScatteringFunc(ShadeRec* sr, const crt_material* mat, float rand_float)
+void computeScatteringFunc(ShadeRec* sr, const crt_material* mat_in, float rand_float, const crt_render_desc* d = 0)
 {
     sr->num_bxdf = 0;
     BxDF b; memset(&b, 0, sizeof b);
     b.rand_float = rand_float;
     const vec3 WHITE = {1.0f, 1.0f, 1.0f};
+    /* Matte_getDiffuseColor / Plastic.diffuse (materials.cpp:51-60,:146-149): the texel at sr->uv replaces color / kd */
+    crt_material textured = *mat_in;
+    const crt_material* mat = mat_in;
+    if (d && d->material_diffuse_tex && sr->mat_index >= 0 && d->material_diffuse_tex[sr->mat_index] >= 0 && sr->has_uv &&
+        (mat_in->type == CRT_MAT_MATTE || mat_in->type == CRT_MAT_PLASTIC)) {
+        getTexColor(textured.color, &d->textures[d->material_diffuse_tex[sr->mat_index]], sr->uv);
+        mat = &textured;
+    }
     switch (mat->type) {
     case CRT_MAT_MATTE:
         vec3_copy(b.color, mat->color);
@@ -1048,14 +1157,17 @@ bool estimateDirect(const Setup& S, vec3 L, const vec2 light_sample, const Shade
         mapSampleToHemisphere(h_sample, light_sample);
         vec3 h_in;
         vec3_copy(h_in, h_sample);
-        orthoNormalTransform(h_sample, sr->b_tangent, sr->b_binormal, sr->b_normal, h_in);   /* transformToLocalBasis; env transform = identity */
+        orthoNormalTransform(h_sample, sr->b_tangent, sr->b_binormal, sr->b_normal, h_in);   /* transformToLocalBasis */
+        vec3 h_copy;
+        vec3_copy(h_copy, h_sample);
+        envTransform(S, h_sample, h_copy);                         /* mat3_mult_vec3(h_sample, env_light->transform, h_copy), trace.h:298-300 */
         vec3 displacement;
         vec3_scale(displacement, h_sample, S.d->env_world_radius);
         vec3_add(sample_point, sr->hit_point, displacement);
         vec3_negate(sample_normal, h_sample);
         vec3_copy(wi, h_sample);
         light_pdf = fabsf(vec3_dot(h_sample, sr->normal)) * INV_PI;
-        vec3_scale(Li, lt.color, lt.intensity);
+        getEnvLightIncRadiance(S, Li, wi);                         /* trace.h:309 */
     }
     vec3 sample_to_hit_point;
     vec3_sub(sample_to_hit_point, sample_point, sr->hit_point);
@@ -1130,7 +1242,11 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
                 }
             } else {
                 vec3 env_inc_radiance = {0.0f, 0.0f, 0.0f};
-                if (S.d->has_env_light) vec3_scale(env_inc_radiance, S.d->env_color, S.d->env_intensity);
+                if (S.d->has_env_light) {                          /* trace.h:436-441 */
+                    vec3 dir;
+                    envTransform(S, dir, ray.d);
+                    getEnvLightIncRadiance(S, env_inc_radiance, dir);
+                }
                 vec3_mult(env_inc_radiance, env_inc_radiance, beta);
                 vec3_add(L, L, env_inc_radiance);
                 good_paths++;
@@ -1140,7 +1256,7 @@ void pathTrace(const Setup& S, vec3 radiance, int depth, const crt_ray primary_r
 
         computeLocalBasis(&sr);
         const uint32_t dim0 = 4 + 8 * (uint32_t)bounces;
-        computeScatteringFunc(&sr, sr.mat, rng(dim0 + 2));         /* dim0 + 2 stands in for rand() inside the lobes */
+        computeScatteringFunc(&sr, sr.mat, rng(dim0 + 2), S.d);    /* dim0 + 2 stands in for rand() inside the lobes */
 
         vec2 light_sample = { rng(dim0 + 0), rng(dim0 + 1) };
         /* scatter_sample: dim0 + 2, dim0 + 3, drawn by the reference and unused */
@@ -1215,6 +1331,7 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
     if (d->has_env_light && d->env_intensity > 0.0f) {             /* buildscene.h:525-533 */
         Light l; l.kind = 0; l.obj_type = -1; l.shape = 0;
         vec3_copy(l.color, d->env_color); l.intensity = d->env_intensity;
+        if (d->env_map) { l.color[0] = l.color[1] = l.color[2] = 1.0f; }   /* EnvLight.color is never set for a map (buildscene.h:479-483): WHITE, shared convention */
         float power = (l.color[0] + l.color[1] + l.color[2]) / 3.0f;
         power *= d->env_intensity * d->env_world_radius;
         l.power = power;
@@ -1243,14 +1360,19 @@ int oracle_render(const oracle_scene* scene, const crt_render_desc* d, const crt
     for (size_t i = 0; i < S.lights.size(); i++) total_power += S.lights[i].power;
     for (size_t i = 0; i < S.lights.size(); i++) S.lights[i].power /= total_power;
 
-    const uint32_t npix = (uint32_t)film->frame_res_width * (uint32_t)film->frame_res_height;
+    /* image rows [row_begin, row_end) (0 / 0 = all): color_buffer holds that band, pixel indices stay those of the frame */
+    int row_begin = d->row_begin, row_end = d->row_end;
+    if (row_begin == 0 && row_end == 0) row_end = film->frame_res_height;
+    if (row_begin < 0 || row_end <= row_begin || row_end > film->frame_res_height) return -1;
+    const uint32_t pix_offset = (uint32_t)row_begin * (uint32_t)film->frame_res_width;
+    const uint32_t npix = (uint32_t)(row_end - row_begin) * (uint32_t)film->frame_res_width;
     auto work = [&](uint32_t b, uint32_t e) {
         for (uint32_t i = b; i < e; i++) {
             for (uint32_t p = first_sample; p < first_sample + num_samples; p++) {
-                Rng rng = { S.seed, i, p };
+                Rng rng = { S.seed, pix_offset + i, p };
                 float isample[2] = { rng(0), rng(1) }, lsample[2] = { rng(2), rng(3) };
                 crt_ray ray;
-                oracle_primary_rays(cam, film, i, 1, isample, lsample, &ray);
+                oracle_primary_rays(cam, film, pix_offset + i, 1, isample, lsample, &ray);
                 vec3 color = {0.0f, 0.0f, 0.0f}, radiance = {0.0f, 0.0f, 0.0f};
                 pathTrace(S, radiance, d->max_depth, ray, rng);
                 vec3_add(color, color, radiance);
@@ -1373,6 +1495,8 @@ void oracle_trace_fresnel_conductor(const float* normal, const float* wo, const 
 {
     calcFresnelConductor(out, normal, wo, etaT, etaI, k);
 }
+void oracle_trace_tex_color(const crt_texture* tex, const float* uv, float* out) { getTexColor(out, tex, uv); }
+void oracle_trace_env_uv(const float* dir, float* uv) { envDirToUV(uv, dir); }
 float oracle_trace_roughness_to_alpha(float roughness) { return BeckmannRoughnessToAlpha(roughness); }
 
 } // extern "C"

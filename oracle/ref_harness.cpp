@@ -812,3 +812,14 @@ REF_API int ref_read_image_state(float* out, int capacity, int* num_samples, int
     if (buf) { memcpy(out, buf, sizeof(float) * (size < capacity ? size : capacity)); free(buf); }
     return size;
 }
+
+/* the lat-long mapping getEnvLightIncRadiance applies before its texel fetch (lights.cpp:241-243): the reference's own
+ * cartesianToSpherical + sphericalToUV (util/math.h:95-107) */
+REF_API void ref_env_uv(const float* dir, float* uv)
+{
+    vec3 in = { dir[0], dir[1], dir[2] };
+    vec2 spherical, out;
+    cartesianToSpherical(spherical, in);
+    sphericalToUV(out, spherical);
+    uv[0] = out[0]; uv[1] = out[1];
+}

@@ -98,6 +98,8 @@ def _load_oracle(path):
         L.oracle_trace_material_bsdf.restype = C.c_float
         L.oracle_trace_beckmann.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp, vp]
         L.oracle_trace_beckmann.restype = None
+        L.oracle_trace_tex_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_trace_env_uv.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_trace_roughness_to_alpha.argtypes = [C.c_float]
         L.oracle_trace_roughness_to_alpha.restype = C.c_float
     return L
@@ -243,7 +245,9 @@ class OracleScene(_SceneBase):
     def render(self, desc, cam, flm, first_sample, num_samples, color_buffer=None, nthreads=8):
         """oracle_render: adds samples [first_sample, first_sample + num_samples) to color_buffer [h, w, 3]."""
         if color_buffer is None:
-            color_buffer = np.zeros((flm.frame_res_height, flm.frame_res_width, 3), np.float32)
+            rows = getattr(desc, "rows", None)
+            h = rows[1] - rows[0] if rows else flm.frame_res_height
+            color_buffer = np.zeros((h, flm.frame_res_width, 3), np.float32)
         assert color_buffer.dtype == np.float32 and color_buffer.flags.c_contiguous
         rc = self.L.oracle_render(self.h, C.byref(desc.c), C.byref(cam), C.byref(flm), int(first_sample), int(num_samples),
                                   color_buffer.ctypes.data, int(nthreads))

@@ -30,8 +30,13 @@ def _worker(rank, world, port, n, out_dir):
     total = shard.sum_over_ranks(float(e - b))
     buf = torch.full((4, 5, 3), float(rank + 1), dtype=torch.float32)
     buf, spp = shard.combine_radiance(buf, 8 * (rank + 1))
+    # tile sharding: each rank "renders" its band of a 7-row frame (a value that depends only on the pixel), all-gather
+    H, W = 7, 5
+    rb, re = shard.tile_rows(H, rank, world)
+    frame = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)
+    tiles = shard.gather_tiles(frame[rb:re].clone(), H, W, rank, world)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), b=b, e=e, vals=vals, worst=worst, total=total,
-             buf=buf.numpy(), spp=spp)
+             buf=buf.numpy(), spp=spp, tiles=tiles.numpy(), rb=rb, re=re)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -48,6 +53,8 @@ def test_two_rank_gloo(tmp_path):
         assert abs(float(p["worst"]) - 0.020) < 1e-12                     # max over ranks
         assert float(p["total"]) == n
         assert np.all(p["buf"] == 3.0) and int(p["spp"]) == 24            # 1 + 2, 8 + 16
+        assert np.array_equal(p["tiles"], np.arange(7 * 5 * 3, dtype=np.float32).reshape(7, 5, 3))   # every rank holds the whole frame
+    assert (int(parts[0]["rb"]), int(parts[0]["re"]), int(parts[1]["rb"]), int(parts[1]["re"])) == (0, 4, 4, 7)   # uneven bands
 
 
 def test_shard_range_properties():
