@@ -286,7 +286,9 @@ const int SAH_BINS = CRT_SAH_BINS;
 #ifndef CRT_SAH_LEAF
 #define CRT_SAH_LEAF 4                              /* objects per leaf of the SAH tree (the reference's rule: 4) */
 #endif
-const int SAH_MAX_DEPTH = 20;                       /* levels; the pruned walk allows 21 (3 * depth + 1 <= 64) */
+/* levels: the pruned walk's stack holds 3 entries per level (3 * 20 + 1 <= 62), the reference-control-flow walk -- which
+ * crt_scene_create picks when an instanced, compound or object-space shape sits under the accelerator -- 4 (4 * 15 + 1 <= 62) */
+const int SAH_MAX_DEPTH_PRUNED = 20, SAH_MAX_DEPTH_EXACT = 15;
 
 inline float box_area(const Box& b)
 {
@@ -386,12 +388,12 @@ int split_range(Builder& B, int first, int count, bool allow_sah, int* axis_out)
 }
 
 /* Appends the subtree of objects [first, first+count) to `out` (indices relative to out's start); returns its root. */
-int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count, int depth)
+int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count, int depth, int max_depth)
 {
     const int self = (int)out.size();
     out.push_back(crt_bvh4_node());
     /* SAH only while a median-split subtree for any part would still fit below the depth limit */
-    const bool allow_sah = depth + 1 + levels_needed(count) <= SAH_MAX_DEPTH;
+    const bool allow_sah = depth + 1 + levels_needed(count) <= max_depth;
     int ax0 = 0, ax1 = 0, ax2 = 0;
     const int mid = split_range(B, first, count, allow_sah, &ax0);
     const int left = split_range(B, first, mid, allow_sah, &ax1);
@@ -422,7 +424,7 @@ int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count
         for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
             std::vector<crt_bvh4_node>* dst = &sub[c];
             const int f = first + start[c], cnt = child_cnt[c];
-            th.emplace_back([&B, dst, f, cnt, depth]() { build4_sah(B, *dst, f, cnt, depth + 1); });
+            th.emplace_back([&B, dst, f, cnt, depth, max_depth]() { build4_sah(B, *dst, f, cnt, depth + 1, max_depth); });
         }
         for (auto& t : th) t.join();
         for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
@@ -436,7 +438,7 @@ int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count
     } else {
         for (int c = 0; c < 4; c++) if (child_cnt[c] > CRT_SAH_LEAF) {
             std::vector<crt_bvh4_node> sub;
-            build4_sah(B, sub, first + start[c], child_cnt[c], depth + 1);
+            build4_sah(B, sub, first + start[c], child_cnt[c], depth + 1, max_depth);
             const int base = (int)out.size();
             nd.child[c] = base;
             for (crt_bvh4_node n : sub) {
@@ -637,8 +639,16 @@ int crt_build_scene_ex(const crt_scene_input* in, int accel, int flags, crt_buil
         const crt_shape& sh = in->shapes[i];
         if (sh.type < 0 || sh.type > CRT_COMPOUND || sh.type == CRT_TRIANGLE) return CRT_E_INVALID;
         if (sh.type == CRT_INSTANCED && (sh.inner < 0 || sh.inner >= in->num_shapes || sh.inner == i)) return CRT_E_INVALID;
+        /* nesting the scene grammar cannot produce and crt_scene_create refuses (an instance of an instance, a compound inside a
+         * compound): refused here too, before shape_box / grid_shape recurse through it -- a two-shape cycle would never return */
+        if (sh.type == CRT_INSTANCED && in->shapes[sh.inner].type == CRT_INSTANCED) return CRT_E_UNSUPPORTED;
         if (sh.type == CRT_COMPOUND && (sh.first_part < 0 || sh.num_parts < 0 || sh.first_part + sh.num_parts > in->num_shapes))
             return CRT_E_INVALID;
+        if (sh.type == CRT_COMPOUND)
+            for (int k = 0; k < sh.num_parts; k++) {
+                const int pt = in->shapes[sh.first_part + k].type;
+                if (pt == CRT_COMPOUND || pt == CRT_INSTANCED) return CRT_E_UNSUPPORTED;
+            }
     }
     crt_built_scene* bs = new (std::nothrow) crt_built_scene();
     if (!bs) return CRT_E_NOMEM;
@@ -670,7 +680,12 @@ int crt_build_scene_ex(const crt_scene_input* in, int accel, int flags, crt_buil
         memset(&B.grid, 0, sizeof B.grid);
         int na = B.n - B.nng;
         if (accel == CRT_ACCEL_BVH4 && na > 0 && (flags & CRT_BUILD_SAH)) {
-            build4_sah(B, B.nodes4, B.nng, na, 0);
+            bool bounded = true;                       /* crt_scene_create's rule for the pruned walk (crt_gpu.hip: accel_bounded) */
+            for (int i = B.nng; i < B.n; i++) {
+                const int t = B.type[i];
+                if (!(is_tri(t) || t == CRT_SPHERE || t == CRT_RECTANGLE || t == CRT_DISK)) bounded = false;
+            }
+            build4_sah(B, B.nodes4, B.nng, na, 0, bounded ? SAH_MAX_DEPTH_PRUNED : SAH_MAX_DEPTH_EXACT);
         } else if (accel == CRT_ACCEL_BVH4 && na > 0) {
             NodeCountCache ncc;
             long long total = na > 4 ? ncc.get(na) : 1;

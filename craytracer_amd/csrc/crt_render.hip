@@ -842,12 +842,25 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         const crt_material& mt = d->materials[m];
         if (mt.type != CRT_MAT_MATTE && mt.type != CRT_MAT_EMISSIVE && mt.type != CRT_MAT_MIRROR && mt.type != CRT_MAT_TRANSPARENT &&
             mt.type != CRT_MAT_PLASTIC && mt.type != CRT_MAT_GLASS && mt.type != CRT_MAT_METAL) return CRT_E_UNSUPPORTED;
+        /* pathTrace paints a path BLUE / RED when a component of its throughput is negative (debug overwrites, trace.h:452-453,
+         * :478-479).  With non-negative colours and PLASTIC ks <= 1 (the Fresnel-blend diffuse lobe scales by 1 - ks,
+         * reflection.cpp:479-496) no lobe value is negative, the throughput never is, and the overwrites cannot trigger;
+         * materials outside those bounds are refused instead of painted */
+        for (int k = 0; k < 3; k++) {
+            if (mt.type != CRT_MAT_METAL && !(mt.color[k] >= 0.0f)) return CRT_E_UNSUPPORTED;      /* METAL: color = eta, k: any sign squared */
+            if (mt.type == CRT_MAT_PLASTIC && !(mt.ks[k] >= 0.0f && mt.ks[k] <= 1.0f)) return CRT_E_UNSUPPORTED;
+        }
     }
     if (d->num_textures < 0 || (d->num_textures > 0 && !d->textures)) return CRT_E_INVALID;
     for (int k = 0; k < d->num_textures; k++) {
         const crt_texture& t = d->textures[k];
         if (t.width < 1 || t.height < 1 || t.comp < 3 || t.comp > 4 || !t.data) return CRT_E_INVALID;    /* getTexColor reads three channels */
         if ((unsigned long long)t.width * (unsigned long long)t.height > (1ull << 28)) return CRT_E_TOOBIG;
+        if (t.is_float) {                                         /* the same bound for float texels (8-bit ones cannot be negative) */
+            const float* px = (const float*)t.data;
+            const size_t count = (size_t)t.width * (size_t)t.height * (size_t)t.comp;
+            for (size_t q = 0; q < count; q++) if (!(px[q] >= 0.0f)) return CRT_E_UNSUPPORTED;
+        }
     }
     if (d->env_map < 0 || d->env_map > d->num_textures) return CRT_E_INVALID;
     if (d->env_map && !d->has_env_light) return CRT_E_INVALID;

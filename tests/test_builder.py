@@ -202,3 +202,41 @@ def test_sah_coincident_triangles_fall_back_to_the_median():
     b = api.BuiltScene(api.SceneInput(v), api.ACCEL_BVH4, sah=True)
     depth, seen = _walk4(b.nodes4, n)
     assert depth <= 20 and sorted(seen) == list(range(n))
+
+
+def test_nested_instances_and_compounds_are_refused_not_recursed_into():
+    """An instance of an instance (a two-shape cycle even: A.inner = B, B.inner = A) or a compound whose part is a compound /
+    instance: CRT_E_UNSUPPORTED from the builder, which would otherwise recurse through them without end."""
+    import ctypes as C
+    L = api.lib()
+    sl = scenes.ShapeList()
+    a = sl._shape(api.INSTANCED, inner=1)
+    b = sl._shape(api.INSTANCED, inner=0)
+    sl._obj(api.INSTANCED, a)
+    sl._obj(api.INSTANCED, b)
+    sl.sphere((0, 0, 0), 1.0)
+    cin = sl.to_input().c_struct()
+    h = C.c_void_p()
+    for accel in (api.ACCEL_NONE, api.ACCEL_GRID, api.ACCEL_BVH, api.ACCEL_BVH4):
+        assert L.crt_build_scene(C.byref(cin), accel, C.byref(h)) == -4          # CRT_E_UNSUPPORTED
+    sl = scenes.ShapeList()
+    inner = sl._shape(api.SPHERE, [0, 0, 0, 1.0, 0.0, 3.14159, 3.14159])
+    sl._shape(api.INSTANCED, inner=inner)                                          # shape 1: an instance, used as a compound part
+    comp = sl._shape(api.COMPOUND, [-1, -1, -1, 1, 1, 1], first_part=1, num_parts=1)
+    sl._obj(api.COMPOUND, comp)
+    cin = sl.to_input().c_struct()
+    assert L.crt_build_scene(C.byref(cin), api.ACCEL_BVH4, C.byref(h)) == -4
+
+
+def test_sah_tree_of_instanced_shapes_fits_the_reference_control_flow_walk():
+    """Instanced shapes under the accelerator make crt_scene_create pick the reference-control-flow walk, whose stack holds four
+    entries per level: the SAH builder then keeps to 15 levels (20 for the pruned walk), adversarial input or not."""
+    n = 3000
+    x = np.cumsum(1.5 ** (np.arange(n) % 40)).astype(np.float64)
+    sl = scenes.ShapeList()
+    for i in range(n):
+        sl.box(scenes.inv_transform((float(x[i]), 0.0, 0.0), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)), 0.1, 0.1, 0.1)
+    si = sl.to_input()
+    b = api.BuiltScene(si, api.ACCEL_BVH4, sah=True)
+    depth, seen = _walk4(b.nodes4, n)
+    assert depth <= 15 and sorted(seen) == list(range(n))

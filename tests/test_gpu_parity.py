@@ -215,3 +215,27 @@ def test_device_pointer_entry_points_and_timer():
     assert ol.same_bits(d_t.cpu().numpy(), o_t)
     assert np.array_equal(d_occ.cpu().numpy().astype(bool), o_occ)
     sc.close()
+
+
+def test_sah_tree_of_instanced_shapes_is_accepted_and_walked():
+    """CRT_BUILD_SAH over instanced boxes: AUTO resolves to the reference-control-flow walk (four stack entries per level), and
+    the builder's 15-level bound for such scenes keeps the tree inside it -- crt_scene_create accepts, hits equal the oracle's."""
+    n = 1500
+    x = np.cumsum(1.5 ** (np.arange(n) % 40)).astype(np.float64)
+    sl = scenes.ShapeList()
+    for i in range(n):
+        sl.box(scenes.inv_transform((float(x[i]), 0.0, 0.0), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)), 0.1, 0.1, 0.1)
+    si = sl.to_input()
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=True)
+    sc = api.Scene(built, 0)
+    assert sc.traverse_mode() == api.TRAVERSE_EXACT
+    rng = np.random.default_rng(4)
+    k = rng.integers(0, n, 4096)
+    o = np.stack([x[k] + rng.uniform(-0.04, 0.04, 4096), np.full(4096, 3.0), rng.uniform(-0.04, 0.04, 4096)], 1)
+    rays = np.concatenate([o, np.tile([0.0, -1.0, 0.0], (4096, 1))], 1).astype(np.float32)
+    rays[:, 3:] += rng.normal(0, 0.003, (4096, 3)).astype(np.float32)
+    g = sc.intersect(rays)
+    w = ol.OracleScene(si, built=built).intersect(rays, mode=api.TRAVERSE_EXACT)
+    assert (w["obj"] >= 0).mean() > 0.25
+    assert np.array_equal(g["obj"], w["obj"]) and close(g["t"], w["t"]).all()
+    sc.close()

@@ -250,6 +250,18 @@ def test_unsupported_scenes_are_refused():
     with pytest.raises(api.CrtError) as e:
         api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
     assert e.value.code == -4
+    # materials that could drive the path throughput negative (where the reference paints the path BLUE / RED, trace.h:452-453,
+    # :478-479): a negative colour, PLASTIC ks above 1
+    mats = desc.materials.copy()
+    mats[0]["color"][1] = -0.1
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
+    assert e.value.code == -4
+    mats = desc.materials.copy()
+    mats[0] = api.material(api.MAT_PLASTIC, (0.5, 0.5, 0.5), ks=(0.2, 1.5, 0.2), uroughness=0.2)
+    with pytest.raises(api.CrtError) as e:
+        api.Renderer(scene, api.RenderDesc(si, desc.obj_material, mats, 3), cam, flm)
+    assert e.value.code == -4
     om = desc.obj_material.copy()
     om[3] = 99
     with pytest.raises(api.CrtError) as e:
