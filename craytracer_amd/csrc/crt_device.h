@@ -471,5 +471,7 @@ CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shado
     if (TRI_ONLY || dev_is_tri(__float_as_int(r2.z)))
         return dev_tri(r0, r1, r2, ray, &h->beta, &h->gamma);
     h->beta = 0.0f; h->gamma = 0.0f;
+    /* rectangles in line: cornell_box.txt (config C1) is rectangles and triangles, and the general path is two out-of-line calls */
+    if (__float_as_int(r2.z) == CRT_RECTANGLE) return dev_rect(sc.shapes[__float_as_int(r2.w)].p, ray, shadow);
     return dev_shape(sc.shapes, __float_as_int(r2.w), ray, shadow, &h->part);
 }

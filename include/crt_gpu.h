@@ -298,20 +298,23 @@ int  crt_film_dimension(crt_film* film, float fov, int res_width, int res_height
 int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* film, uint32_t first_pixel, size_t n,
                           const float* d_image_samples, const float* d_lens_samples, crt_ray* d_rays, void* stream);
 
-/* ---- wavefront path tracing (restricted form) ------------------ */
+/* ---- wavefront path tracing ------------------------------------ */
 /* pathTrace (trace.h:399-532) + uniformSampleOneLight (:359-397) + estimateDirect (:221-357) +
  * the per-pixel sample loop of threadFunc (main.cpp:88-149), turned from "one path per call" into
- * "one bounce of every path per kernel": generate -> { extend (crt_intersect_batch_dev) -> shade ->
- * shadow (crt_shadow_batch_dev) -> accumulate } x (max_depth + 1) -> add to the colour buffer.
- * Restrictions of this form (anything else: CRT_E_UNSUPPORTED at create):
- *   geometry  TRIANGLE, FLAT_TRIANGLE, SMOOTH_TRIANGLE (interpolated normals; needs crt_mesh_shading), RECTANGLE,
- *             SPHERE; DISK only with an EMISSIVE material;
- *   materials every MatType, without textures: MATTE (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR
+ * "one bounce of every path per kernel": generate -> { extend (crt_intersect_batch_dev_counted) -> shade ->
+ * shadow (crt_shadow_batch_dev_counted) -> accumulate } x (max_depth + 1) -> add to the colour buffer.
+ * What it takes (anything else: CRT_E_UNSUPPORTED at create):
+ *   geometry  every object type.  SMOOTH_TRIANGLE needs crt_mesh_shading.  Fields the reference's intersectors never write
+ *             but pathTrace reads get the conventions listed at crt_fill_shade_rec (dpdu of triangles, planes, disks, boxes,
+ *             cylinders, tori; the back of a disk; a torus hit outside its phi window);
+ *   materials every MatType: MATTE (Lambertian, or Oren-Nayar when sigma != 0, materials.cpp:116-128), MIRROR
  *             (specular reflection, :129-136), TRANSPARENT (thin specular transmission, :137-141), PLASTIC (Fresnel-blend
- *             diffuse + specular lobes, :142-171), GLASS (rough dielectric, :172-178), METAL (:179-186), EMISSIVE;
+ *             diffuse + specular lobes, :142-171), GLASS (rough dielectric, :172-178), METAL (:179-186), EMISSIVE; colours
+ *             >= 0 and PLASTIC ks <= 1 (outside those bounds the reference paints paths BLUE / RED, trace.h:452-453,:478-479);
+ *   textures  Matte.diffuse / Plastic.diffuse on FLAT_TRIANGLE / SMOOTH_TRIANGLE objects (crt_texture below); no normal maps;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
- *             (initAreaLights, buildscene.h:567-608) and one constant EnvLight (identity transform); EMISSIVE
- *             triangles of any kind emit when a path finds them and are never sampled (the reference's MeshLights
+ *             (initAreaLights, buildscene.h:567-608) and one EnvLight, constant or a lat-long map, behind EnvLight.transform;
+ *             EMISSIVE triangles of any kind emit when a path finds them and are never sampled (the reference's MeshLights
  *             carry no power, buildscene.h:879-917, and estimateDirect has no case for them, trace.h:311-313).
  * Random numbers: the reference draws from per-thread sample tables (Sampler_getSample) and from libc
  * rand() (trace.h:371,:516), both dependent on thread scheduling.  Here every number is
