@@ -359,7 +359,7 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid) return launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false, true>, la, st, true, na);
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) return launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false, true>, la, st, true, na);
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)

@@ -254,6 +254,8 @@ CRT_DEV float cnode_key(float tnx, float tny, float tnz, float tfx, float tfy, f
 }
 #define CRT_UB(w, c) ((float)(((w) >> (8 * (c))) & 0xFFu))       /* v_cvt_f32_ubyteN */
 /* keys of the four children of compressed node `nb` (byte offset); sx / sy / sz: direction component >= 0 */
+CRT_DEV void cnode_keys_regs(const uint4 c0, const uint4 c1, const uint4 c2, const DRay& r, float ia, float ib, float ic,
+                             bool sx, bool sy, bool sz, float* k0, float* k1, float* k2, float* k3);
 CRT_DEV void cnode_keys(const uint4* cnodes, unsigned nb, const DRay& r, float ia, float ib, float ic, bool sx, bool sy, bool sz,
                         float* k0, float* k1, float* k2, float* k3, uint4* words)
 {
@@ -262,6 +264,12 @@ CRT_DEV void cnode_keys(const uint4* cnodes, unsigned nb, const DRay& r, float i
     const uint4 c1 = *reinterpret_cast<const uint4*>(cb + (nb + 16u));
     const uint4 c2 = *reinterpret_cast<const uint4*>(cb + (nb + 32u));
     *words = *reinterpret_cast<const uint4*>(cb + (nb + 48u));
+    cnode_keys_regs(c0, c1, c2, r, ia, ib, ic, sx, sy, sz, k0, k1, k2, k3);
+}
+/* the same from a node already in registers */
+CRT_DEV void cnode_keys_regs(const uint4 c0, const uint4 c1, const uint4 c2, const DRay& r, float ia, float ib, float ic,
+                             bool sx, bool sy, bool sz, float* k0, float* k1, float* k2, float* k3)
+{
     float anx, afx, bx, any_, afy, by, anz, afz, bz;
     cnode_axis(__uint_as_float(c0.x), __uint_as_float(c0.w), r.ox, ia, &anx, &afx, &bx);
     cnode_axis(__uint_as_float(c0.y), __uint_as_float(c1.x), r.oy, ib, &any_, &afy, &by);
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
     resolve_count(la);
     /* PENDING: the conservative-node walk keeps the leaf it is testing in a register of its own (`pl`) and walks on while
      * the leaf's remaining objects are tested, one per iteration, next to the node steps (see the loop below). */
-    constexpr bool PENDING = COMPRESSED && !EXACT && CRT_PENDING_LEAF;
+    constexpr bool PENDING = COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF;
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
@@ -514,8 +522,23 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
     float cur_min = CRT_TMAX;     /* EXACT: min_t of the innermost open node visit */
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
-    /* One node visit of the lane's `cur`: the four keys, then the children that pass are pushed in reverse visiting order and
-     * the first becomes `cur`.  Returns false when no child passes (the lane has to pop). */
+    /* The children whose keys pass are pushed in reverse visiting order and the first becomes `cur`; false = none passed. */
+    auto order_push = [&](int ax2, float k0, float k1, float k2, float k3, unsigned w0, unsigned w1, unsigned w2, unsigned w3)
+                      __attribute__((always_inline)) -> bool {
+        const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
+        /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
+        const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
+        const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
+        const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
+        const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
+        const float thr = EXACT ? cur_min : best_t;                       /* EXACT: TMAX here, the visit has just opened */
+        if (s3k < thr) st.push(s3w, s3k);
+        if (s2k < thr) st.push(s2w, s2k);
+        if (s1k < thr) st.push(s1w, s1k);
+        if (s0k < thr) { cur = s0w; return true; }
+        return false;
+    };
+    /* One node visit of the lane's `cur`: the four keys, then order_push.  Returns false when no child passes (the lane has to pop). */
     auto node_step = [&]() __attribute__((always_inline)) -> bool {
         /* inner child word = (axis2 of that node) << 28 | node index (< 2^25: 32-bit byte offsets) */
         const int ax2 = (int)((cur >> 28) & 3u);
@@ -554,18 +577,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
             w0 = __float_as_uint(q6.x); w1 = __float_as_uint(q6.y);
             w2 = __float_as_uint(q6.z); w3 = __float_as_uint(q6.w);
         }
-        const bool p2 = ((pbits >> ax2) & 1u) != 0u;                      /* bvh4.h:323,:334: d[axis2] > 0 */
-        /* visiting sequence: px ? (0, 1, C, D) : (C, D, 1, 0) with (C, D) = p2 ? (2, 3) : (3, 2) */
-        const float kC = p2 ? k2 : k3, kD = p2 ? k3 : k2;
-        const unsigned wC = p2 ? w2 : w3, wD = p2 ? w3 : w2;
-        const float s0k = px ? k0 : kC, s1k = px ? k1 : kD, s2k = px ? kC : k1, s3k = px ? kD : k0;
-        const unsigned s0w = px ? w0 : wC, s1w = px ? w1 : wD, s2w = px ? wC : w1, s3w = px ? wD : w0;
-        const float thr = EXACT ? cur_min : best_t;                       /* EXACT: TMAX here, the visit has just opened */
-        if (s3k < thr) st.push(s3w, s3k);
-        if (s2k < thr) st.push(s2w, s2k);
-        if (s1k < thr) st.push(s1w, s1k);
-        if (s0k < thr) { cur = s0w; return true; }
-        return false;
+        return order_push(ax2, k0, k1, k2, k3, w0, w1, w2, w3);
     };
     /* the object at objects[first] against the ray: strict `<`, array order (bvh4.h:374-383) */
     auto object_step = [&](int first) __attribute__((always_inline)) {
