@@ -498,7 +498,7 @@ def main():
     accel_name = {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel]
     tree = ("SAH split planes (crt_build_scene_ex CRT_BUILD_SAH: the reference's node format, leaf rule and walk; not the tree the "
             "reference's builder makes)" if args.builder == "sah" else "the reference's median split (bvh4.h:127-297)")
-    kname = {"bvh4": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest<tri_only>", "bvh": "k_bvh2<tri_only>", "grid": "k_grid<tri_only>"}[args.accel]
+    kname = {"bvh4": "k_bvh4_shadow<tri_only>" if shadow else "k_bvh4_closest_tri", "bvh": "k_bvh2<tri_only>", "grid": "k_grid<tri_only>"}[args.accel]
     tkey = "%s@%s%s" % (args.workload, args.builder, "/shadow" if shadow else "")
     out = {
         "metric": ("Mrays/s any-hit (shadow rays toward an area light), %s" if shadow else "Mrays/s closest-hit (incoherent), %s") % accel_name,
@@ -569,7 +569,7 @@ def main():
                                      "hits_checksum": r_chk,
                                      "hit_records_differing_from_sah_tree": int(differ.sum().item()),
                                      "of_which_exact_t_ties": int(ties.sum().item()),
-                                     "roofline": roofline("k_bvh4_closest<tri_only>", float(np.mean(r_kms[1:])), float(np.mean(r_bms[1:])),
+                                     "roofline": roofline("k_bvh4_closest_tri", float(np.mean(r_kms[1:])), float(np.mean(r_bms[1:])),
                                                           rc["nodes_visited"] / n, rc["prims_tested"] / n,
                                                           "%s@reference" % args.workload, r_chk, n)}
             del r_hits

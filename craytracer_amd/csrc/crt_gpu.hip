@@ -359,7 +359,7 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) return launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false, true>, la, st, true, na);
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) return launch(s, k_bvh4_closest_tri<COUNT>, la, st, true, na);
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
     case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
@@ -954,8 +954,17 @@ int crt_scene_get_counters(crt_scene* s, crt_counters* out)
     out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_visited = h[2]; out->prims_tested = h[3];
 #if CRT_DIAG
     {
-        unsigned long long d[9];
+        unsigned long long d[24];
         HIPCHK(hipMemcpy(d, s->d_counters + 8, sizeof d, hipMemcpyDeviceToHost));
+        {
+            unsigned long long t4[4];
+            HIPCHK(hipMemcpy(t4, s->d_counters + 4, sizeof t4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[diag] tail (after the wave's queue ran dry): %llu wave-iterations in all, longest wave %llu, alive lanes per tail iteration %.2f, hand-overs %llu\n",
+                    t4[0], t4[3], t4[0] ? (double)t4[1] / t4[0] : 0.0, t4[2]);
+        }
+        fprintf(stderr, "[diag] iterations per ray: max %llu; rays by floor(log2(iterations)) 0..11+:", d[11]);
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", d[12 + k]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[diag] wave-iterations %llu  alive/it %.2f  walking/it %.2f  node lanes/it %.2f  object lanes/it %.2f  stalled/it %.2f  iterations with a node step %.3f  with an object step %.3f\n",
                 d[0], (double)d[1] / d[0], (double)d[8] / d[0], (double)d[2] / d[0], (double)d[3] / d[0], (double)d[5] / d[0], (double)d[6] / d[0], (double)d[7] / d[0]);
     }

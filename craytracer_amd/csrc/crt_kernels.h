@@ -17,7 +17,7 @@
  * are resident per CU -- at 16 deep (32 KB) only four fit in the 160 KB, and the fifth wave per SIMD is worth 8 % (1 813 ->
  * 1 954 Mrays/s; 12 deep: 1 915, six waves at 80 VGPRs and 12 / 13 deep: 1 844 / 1 854).  4-byte entries (any-hit walks): 16 deep. */
 #ifndef CRT_LDS_DEPTH
-#define CRT_LDS_DEPTH  14
+#define CRT_LDS_DEPTH  14          /* (13 when the headline kernel's 4 KB of tail-splitting slots are compiled in: 30 KB, still five per CU) */
 #endif
 #ifndef CRT_LDS_DEPTH32
 #define CRT_LDS_DEPTH32 16
@@ -359,6 +359,14 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #ifndef CRT_DIAG
 #define CRT_DIAG 0                /* diagnostic build: per-iteration lane statistics of the closest-hit walk into counters[8..] */
 #endif
+/* ordering of the tail-splitting slots (LDS, touched by the lanes of one wave only) */
+#define CRT_WG_FENCE()    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#ifndef CRT_STEAL_BOTTOM
+#define CRT_STEAL_BOTTOM 0
+#endif
+#ifndef CRT_TAIL_SPLIT
+#define CRT_TAIL_SPLIT 0          /* experiment, off: see "tail splitting" in k_bvh4_closest's loop and DESIGN.md (build with -DCRT_TAIL_SPLIT=1 -DCRT_LDS_DEPTH=13) */
+#endif
 #ifndef CRT_PENDING_LEAF
 #define CRT_PENDING_LEAF 1
 #endif
@@ -489,14 +497,17 @@ struct RayFeed {
  * the marker (all of the node's children done) folds the node's result into the parent's:
  * `if (t < min_t) min_t = t` (bvh4.h:366-370).  The hit record that survives this chain of strict
  * comparisons is the first-found global minimum, which best_t / best track as in the pruned walk. */
-template <bool TRI_ONLY, bool COUNT, bool EXACT = false, bool COMPRESSED = false>
-__global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevScene sc, LaunchArgs la)
+template <bool TRI_ONLY, bool COUNT, bool EXACT, bool COMPRESSED>
+CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
     /* PENDING: the conservative-node walk keeps the leaf it is testing in a register of its own (`pl`) and walks on while
      * the leaf's remaining objects are tested, one per iteration, next to the node steps (see the loop below). */
     constexpr bool PENDING = COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF;
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
+    /* tail splitting: one slot per lane, {(t bits, object) of the best hit of the ray's pieces; pieces pending | tie << 32} */
+    __shared__ unsigned long long s_slot[(COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF && CRT_TAIL_SPLIT) ? 2 : 1]
+                                        [(COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF && CRT_TAIL_SPLIT) ? CRT_BLOCK : 1];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
     LaneStack st;
     st.lds = s_stack;
@@ -509,6 +520,18 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
     bool alive = false;
     unsigned ri = 0, cur = 0;
     unsigned pl = 0;              /* PENDING: leaf word whose objects are being tested (count field 0 = none) */
+    /* tail splitting (see the block at the top of the loop): bottom of this lane's stack (entries below were given away), the group
+     * this lane's piece belongs to, and the final-order index of the best object found (what the pieces' results are merged on) */
+    constexpr bool STEAL = PENDING && CRT_TAIL_SPLIT;
+    /* bit 0: piece of a split ray; bit 1: never split this ray (re-walk after a tie); bits 8..13: slot.  In a piece the best
+     * object's final-order index rides in best.part (0 for every triangle, and written as 0); best.obj < 0 with best_t < TMAX
+     * means the bound came from another piece. */
+    unsigned grp = 0;
+#if CRT_STEAL_BOTTOM
+    #define SBASE ((int)(grp >> 16))          /* bits 16..: bottom of this lane's stack (entries below were given away) */
+#else
+    #define SBASE 0
+#endif
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
     bool px = true, walking = false;
@@ -584,12 +607,22 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
         DHit h;
         const float t = dev_object<TRI_ONLY>(sc, first, ray, false, &h);
         if (COUNT) c_prims++;
-        if (t < best_t) { best_t = t; best = h; }
+        if (t < best_t || (STEAL && (grp & 1u) && best.obj < 0 && t == best_t && t < CRT_TMAX)) {
+            best_t = t; best = h;
+            if (STEAL) {
+                best.part = first;
+                if (grp & 1u) {                                    /* a piece of a split ray: the other pieces prune with this hit from now on */
+                    const unsigned si = (threadIdx.x & ~63u) + ((grp >> 8) & 63u);
+                    const unsigned long long old = atomicMin(&s_slot[0][si], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)first);
+                    if ((unsigned)(old >> 32) == __float_as_uint(t) && (unsigned)old != (unsigned)first) atomicOr(&s_slot[1][si], 1ull << 32);
+                }
+            }
+        }
         if (EXACT && t < cur_min) cur_min = t;                             /* bvh4.h:378-382, the open node's min_t */
     };
     /* pops until an entry survives the cull against the nearest hit so far; false = the stack is empty */
     auto pop_next = [&]() __attribute__((always_inline)) -> bool {
-        while (st.sp > 0) {
+        while (st.sp > SBASE) {
             unsigned w; float key;
             st.pop(&w, &key);
             if (EXACT && w == CRT_FRAME_MARK) {                            /* the node visit closes: bvh4.h:366-370 */
@@ -601,43 +634,134 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
         return false;
     };
 
+    /* what a lane derives from a ray it has just been given, and the start of the walk at the root */
+    auto start_ray = [&]() __attribute__((always_inline)) {
+        cur_min = CRT_TMAX;
+        ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
+        const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
+        onx = sx ? 0u : 48u;  ofx = 48u - onx;
+        ony = sy ? 16u : 64u; ofy = 80u - ony;
+        onz = sz ? 32u : 80u; ofz = 112u - onz;
+        px = ray.dx > 0.0f;                                                    /* bvh4.h:312 (axis0 = axis1 = 0) */
+        pbits = (px ? 1u : 0u) | (ray.dy > 0.0f ? 2u : 0u) | (ray.dz > 0.0f ? 4u : 0u);
+        /* finite non-zero 1/d and a finite origin: every (plane - o) * (1/d) is then a number
+         * (possibly +-inf), never NaN, and max3 / min3 equal the SSE max / min chains */
+        clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
+                fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
+                ia != 0.0f && ib != 0.0f && ic != 0.0f;
+        /* compressed nodes: (origin - o) * (1/d) and 255 * scale * (1/d) must stay far from overflow (boxes are < 1e30) */
+        if (COMPRESSED) clean = clean && fabsf(ia) < 1.0e6f && fabsf(ib) < 1.0e6f && fabsf(ic) < 1.0e6f;
+        best_t = CRT_TMAX;
+        best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+        st.sp = 0; grp = 0u;
+        cur = sc.root_word;
+        pl = 0u;
+        walking = sc.n_accel > 0;
+        alive = true;
+    };
+
     RayFeed<false> feed;
     feed.start(la);
 #if CRT_DIAG
     unsigned d_it = 0, d_alive = 0, d_node = 0, d_obj = 0, d_pop = 0, d_stall = 0, d_nodeit = 0, d_objit = 0, d_walk = 0;
+    unsigned d_ray_it = 0;        /* iterations the lane's current ray has been in flight */
+    unsigned d_tail_it = 0, d_tail_alive = 0, d_steals = 0, d_tail_max = 0;
 #endif
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
         if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN) {
             float unused_ld;
-            if (feed.take(la, idle, !alive, &ri, &ray, &unused_ld)) {
-                cur_min = CRT_TMAX;
-                ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* bvh4.h:26-28 */
-                const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;   /* bvh4.h:43,:54,:65 */
-                onx = sx ? 0u : 48u;  ofx = 48u - onx;
-                ony = sy ? 16u : 64u; ofy = 80u - ony;
-                onz = sz ? 32u : 80u; ofz = 112u - onz;
-                px = ray.dx > 0.0f;                                                    /* bvh4.h:312 (axis0 = axis1 = 0) */
-                pbits = (px ? 1u : 0u) | (ray.dy > 0.0f ? 2u : 0u) | (ray.dz > 0.0f ? 4u : 0u);
-                /* finite non-zero 1/d and a finite origin: every (plane - o) * (1/d) is then a number
-                 * (possibly +-inf), never NaN, and max3 / min3 equal the SSE max / min chains */
-                clean = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX &&
-                        fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f &&
-                        ia != 0.0f && ib != 0.0f && ic != 0.0f;
-                /* compressed nodes: (origin - o) * (1/d) and 255 * scale * (1/d) must stay far from overflow (boxes are < 1e30) */
-                if (COMPRESSED) clean = clean && fabsf(ia) < 1.0e6f && fabsf(ib) < 1.0e6f && fabsf(ic) < 1.0e6f;
-                best_t = CRT_TMAX;
-                best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
-                st.sp = 0;
-                cur = sc.root_word;
-                pl = 0u;
-                walking = sc.n_accel > 0;
-                alive = true;
-            }
+            if (feed.take(la, idle, !alive, &ri, &ray, &unused_ld)) start_ray();
             if (__ballot(alive && !clean) != 0ull) wave_clean = false;
+        }
+        /* ---- tail splitting ----------------------------------------------------------------------------------------------
+         * Once the queue has nothing more for this wave, its lanes run dry one by one while the longest rays walk on alone
+         * (per wave 137 iterations on average and up to 476 on the 10.5 M-triangle scene, with 12 lanes alive).  A pending
+         * stack entry is an independent
+         * subtree, so in that phase an idle lane takes the TOP entry (the subtree the walk would enter next: the one most likely to be
+         * needed -- the bottom ones are mostly culled once a near hit is found) of a lane that still has some, with a copy of the
+         * ray and of its best t as a pruning bound.  The pieces of a ray form a group with one slot in memory: every hit a piece
+         * finds goes into it with a 64-bit atomic min on (t bits, final-order object index), every piece reads the slot's t once
+         * per iteration and prunes with it, and the piece that finishes last re-runs the triangle test on the winner and
+         * writes the hit record.  The
+         * nearest t is independent of the order in which subtrees are walked; WHICH of several exactly-equal-t objects wins
+         * is not, so when two pieces report the same t for different objects the ray is walked again from the root, by one
+         * lane, unsplit (ties are a handful per 2^24 rays). */
+        if (STEAL && feed.empty) {
+            /* givers: at least two pending entries, all in LDS, the top one an inner node (a leaf is not worth a hand-over) */
+#if CRT_STEAL_BOTTOM
+            bool can_give = alive && !(grp & 2u) && st.sp > SBASE + 1 && SBASE < CRT_LDS_DEPTH;
+            if (can_give) can_give = !(s_stack[SBASE][threadIdx.x].x & CRT_LEAF_BIT);
+#else
+            bool can_give = alive && !(grp & 2u) && st.sp > 1 && st.sp <= CRT_LDS_DEPTH;
+            if (can_give) can_give = !(s_stack[st.sp - 1][threadIdx.x].x & CRT_LEAF_BIT);
+#endif
+            const unsigned long long give_m = __ballot(can_give), idle_m = __ballot(!alive);
+            if (give_m != 0ull && idle_m != 0ull) {
+                const unsigned n_give = (unsigned)__popcll(give_m), n_idle = (unsigned)__popcll(idle_m);
+                const unsigned n_pair = n_give < n_idle ? n_give : n_idle;
+                const unsigned lane = threadIdx.x & 63u;
+                const unsigned wave0 = threadIdx.x & ~63u;          /* this wave's 64 slots */
+                const bool giving = can_give && lane_rank(give_m) < n_pair;
+                unsigned e_w = 0u, e_k = 0u;
+                if (giving) {
+#if CRT_STEAL_BOTTOM
+                    const StackEntry e = s_stack[SBASE][threadIdx.x];
+                    grp += 1u << 16;
+#else
+                    st.sp--;
+                    const StackEntry e = s_stack[st.sp][threadIdx.x];
+#endif
+                    e_w = e.x; e_k = e.y;
+                    if (!(grp & 1u)) {                               /* first split of this ray: open its group in this lane's slot */
+                        grp |= 1u | (lane << 8);
+                        const unsigned long long key0 = best.obj >= 0 ? (((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)best.part) : ~0ull;
+                        s_slot[0][wave0 + lane] = key0;
+                        s_slot[1][wave0 + lane] = 1ull;              /* pieces pending: this one */
+                        CRT_WG_FENCE();
+                    }
+                    atomicAdd(&s_slot[1][wave0 + ((grp >> 8) & 63u)], 1ull);
+                    CRT_WG_FENCE();
+                }
+                /* the k-th idle lane takes from the k-th giving lane */
+                unsigned k = lane_rank(idle_m), src = 0u;
+                {
+                    unsigned long long m = give_m;
+                    for (unsigned sh = 32u; sh >= 1u; sh >>= 1) {
+                        const unsigned c = (unsigned)__popcll(m & ((1ull << sh) - 1ull));
+                        if (k >= c) { k -= c; m >>= sh; src += sh; }
+                    }
+                }
+                const int a = (int)((src & 63u) << 2);
+                const bool taking = !alive && lane_rank(idle_m) < n_pair;
+                /* every value moves straight into the taking lane's own register (givers are alive lanes, takers idle ones: no
+                 * lane is both), so the copies do not pile up in registers */
+                #define CRT_TAKE_U(x) { const unsigned t_ = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)(x)); if (taking) (x) = t_; }
+                #define CRT_TAKE_F(x) { const float t_ = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(x))); if (taking) (x) = t_; }
+                CRT_TAKE_U(ri)
+                CRT_TAKE_F(ray.ox) CRT_TAKE_F(ray.oy) CRT_TAKE_F(ray.oz) CRT_TAKE_F(ray.dx) CRT_TAKE_F(ray.dy) CRT_TAKE_F(ray.dz)
+                const float v_bt = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(best_t)));
+                const unsigned v_grp = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)grp);
+                CRT_TAKE_U(e_w) CRT_TAKE_U(e_k)
+                #undef CRT_TAKE_U
+                #undef CRT_TAKE_F
+#if CRT_DIAG
+                if (COUNT) d_steals += n_pair;
+#endif
+                if (taking) {
+                    start_ray();
+                    grp = v_grp & 0x3FFFu;
+                    best_t = v_bt;                                   /* a bound to prune with; `best` stays empty until this piece finds a hit */
+                    cur = e_w;
+                    walking = __uint_as_float(e_k) < v_bt;
+                }
+                if (__ballot(alive && !clean) != 0ull) wave_clean = false;
+            }
         }
         if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
 #if CRT_DIAG
+        if (COUNT && feed.empty) { d_tail_it++; d_tail_alive += (unsigned)__popcll(__ballot(alive)); }
+        if (COUNT && alive) d_ray_it++;
         if (COUNT) {
             const bool inner = alive && walking && !(cur & CRT_LEAF_BIT);
             const bool leafcur = alive && walking && (cur & CRT_LEAF_BIT);
@@ -660,9 +784,16 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
                  * against a nearest hit that is up to three objects stale, i.e. a few more children get pushed (they are culled
                  * again, against the current value, when popped). */
                 bool need_pop = false;
+                unsigned long long group_key = ~0ull;
+                if (STEAL && (grp & 1u))                             /* what the ray's other pieces have found so far (read past the L1) */
+                    group_key = *(volatile unsigned long long*)&s_slot[0][(threadIdx.x & ~63u) + ((grp >> 8) & 63u)];
                 if (walking) {
                     if (!(cur & CRT_LEAF_BIT)) need_pop = !node_step();
                     if ((cur & CRT_LEAF_BIT) && !need_pop && ((pl >> 28) & 7u) == 0u) { pl = cur; need_pop = true; }
+                }
+                if (STEAL && (grp & 1u) && __uint_as_float((unsigned)(group_key >> 32)) < best_t && group_key != ~0ull) {
+                    best_t = __uint_as_float((unsigned)(group_key >> 32));
+                    best.obj = -1;                                   /* a bound, not this piece's hit */
                 }
                 const unsigned pcount = (pl >> 28) & 7u;
                 if (pcount > 0u) {
@@ -672,10 +803,40 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
                 }
                 if (need_pop) walking = pop_next();
                 if (!walking && ((pl >> 28) & 7u) == 0u) {
-                    linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
-                    store_hit(la.hits, ri, best_t, best);
-                    if (COUNT) c_rays++;
                     alive = false;
+                    if (STEAL && (grp & 1u)) {
+                        /* a piece of a split ray: merge, and if it is the last one, settle the ray */
+                        const unsigned si = (threadIdx.x & ~63u) + ((grp >> 8) & 63u);
+                        CRT_WG_FENCE();                              /* this piece's hits went into the slot as they were found */
+                        const unsigned long long before = atomicAdd(&s_slot[1][si], ~0ull);     /* pending - 1 */
+                        if ((unsigned)before == 1u) {
+                            CRT_WG_FENCE();
+                            const unsigned long long key = atomicMin(&s_slot[0][si], ~0ull);
+                            const bool tie = (atomicOr(&s_slot[1][si], 0ull) >> 32) != 0ull;
+                            if (tie) {                               /* equal t from two pieces: which object wins is a matter of walk order */
+                                start_ray();
+                                grp = 2u;
+                            } else {
+                                DHit h; h.obj = -1; h.part = -1; h.beta = 0.0f; h.gamma = 0.0f;
+                                float t = CRT_TMAX;
+                                if (key != ~0ull) t = dev_object<TRI_ONLY>(sc, (int)(unsigned)key, ray, false, &h);
+                                store_hit(la.hits, ri, t, h);
+                                if (COUNT) c_rays++;
+                            }
+                        }
+                    } else {
+                        if (STEAL) best.part = 0;
+                        linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &best_t, &best, &c_prims);
+                        store_hit(la.hits, ri, best_t, best);
+                        if (COUNT) c_rays++;
+                    }
+#if CRT_DIAG
+                    if (COUNT) {                                   /* histogram of iterations per ray: bucket = floor(log2), and the maximum */
+                        atomicAdd(&sc.counters[20 + (31 - __clz((int)(d_ray_it | 1u)) < 11 ? 31 - __clz((int)(d_ray_it | 1u)) : 11)], 1ull);
+                        atomicMax(&sc.counters[19], (unsigned long long)d_ray_it);
+                        d_ray_it = 0;
+                    }
+#endif
                 }
             } else {
                 if (walking) {
@@ -706,8 +867,26 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
     if (COUNT && (threadIdx.x & 63) == 0) {
         const unsigned v[9] = { d_it, d_alive, d_node, d_obj, d_pop, d_stall, d_nodeit, d_objit, d_walk };
         for (int k = 0; k < 9; k++) atomicAdd(&sc.counters[8 + k], (unsigned long long)v[k]);
+        atomicAdd(&sc.counters[4], (unsigned long long)d_tail_it);
+        atomicAdd(&sc.counters[5], (unsigned long long)d_tail_alive);
+        atomicAdd(&sc.counters[6], (unsigned long long)d_steals);
+        atomicMax(&sc.counters[7], (unsigned long long)d_tail_it);
     }
 #endif
+}
+
+template <bool TRI_ONLY, bool COUNT, bool EXACT = false>
+__global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevScene sc, LaunchArgs la)
+{
+    bvh4_closest_body<TRI_ONLY, COUNT, EXACT, false>(sc, la);
+}
+/* The headline kernel: triangle-only scene, pruned walk over the conservative nodes, pending leaf, tail splitting.  A kernel of
+ * its own so that its register budget (five waves per SIMD: 96 VGPRs; the tail-splitting block would otherwise take it to 104
+ * and the fifth wave is worth 8 %) does not bind the other instantiations of the body. */
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bvh4_closest_tri(DevScene sc, LaunchArgs la)
+{
+    bvh4_closest_body<true, COUNT, false, true>(sc, la);
 }
 
 /* =====================================================================================

@@ -21,7 +21,7 @@ for d in sorted(os.listdir(src)):
         continue
     builder, mode = d.rsplit("_", 1)
     line = json.loads(open(os.path.join(full, "bench_line.json")).read())
-    want = "k_bvh4_shadow<true, false" if mode == "shadow" else "k_bvh4_closest<true, false, false"
+    want = "k_bvh4_shadow<true, false" if mode == "shadow" else "k_bvh4_closest_tri<false"
     vals, cur = {}, None
     for ln in open(os.path.join(full, "summary.txt")):
         if ln.startswith("kernel:"):
