@@ -514,7 +514,9 @@ def main():
                    "traverse_mode": ("reference order, first hit ends the walk" if args.accel != "bvh" else "min t over the tree, best-t pruned")
                    if shadow else ("pruned" if args.accel != "grid" else "3D-DDA as written"),
                    "parallelism": "scene replica per GPU, rays sharded, no collective", "ray_binning": args.binning, "builder": args.builder,
-                   "node_format": "64-byte conservative copy (4 x 16 B per visit)" if compressed_nodes else "128-byte nodes (7 x 16 B per visit)",
+                   "node_format": {"bvh": "64-byte records of both child boxes (4 x 16 B per visit), nearer child first",
+                                   "grid": "cell_start[] pairs + cell_items[]"}.get(args.accel)
+                   or ("64-byte conservative copy (4 x 16 B per visit)" if compressed_nodes else "128-byte nodes (7 x 16 B per visit)"),
                    "hit_fraction": round(hit_frac, 4), "hits_checksum": checksum, "src_hash": shash, "scene_build_s": round(build_s, 2)},
         "roofline": roofline(kname, avg_kernel_ms, float(np.mean(bin_ms)), nodes_per_ray, tris_per_ray, tkey, checksum, rays_per_launch),
     }

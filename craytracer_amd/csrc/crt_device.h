@@ -40,6 +40,7 @@ struct DevScene {
     const float4* nodes2;
     const int* cell_start;
     const int* cell_items;
+    const unsigned char* cell_dist;    /* per cell: chessboard distance to the nearest occupied cell (0: occupied), crt_gpu.hip grid_distance_field */
     unsigned long long* counters;   /* [4]: rays_closest, rays_shadow, nodes, prims */
     crt_grid grid;
     int num_obj;

@@ -13,7 +13,9 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #include <new>
 #include <mutex>
 #include <atomic>
@@ -70,9 +72,11 @@ struct crt_scene {
     bool count;
     bool compress;            /* walk the 64-byte conservative copy of the QBVH nodes where that is allowed (see crt_scene_set_node_compression) */
     bool cnodes_valid;        /* the copy exists (every node box was finite) */
+    bool bvh2_ordered;        /* binary BVH: left-first depth-first order meets the leaves in increasing object index, so the pruned
+                                 walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items;
+    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items; void* d_cell_dist;
     unsigned long long* d_counters;
     Scratch own;              /* allocated by crt_scene_create (perm may grow) */
     Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
@@ -92,6 +96,10 @@ struct crt_scene {
     bool binning; BinGrid bin_grid; bool bin_grid_valid;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
+
+#ifndef CRT_NODE_ORDER_DEFAULT
+#define CRT_NODE_ORDER_DEFAULT 1
+#endif
 
 namespace {
 
@@ -129,6 +137,116 @@ int depth2(const crt_scene_desc* d)
         if (n.left >= 0) { stack.push_back(std::make_pair(n.left, e.second + 1)); stack.push_back(std::make_pair(n.right, e.second + 1)); }
     }
     return best;
+}
+
+
+/* Order of the QBVH nodes in device memory (results do not depend on it: child words are renumbered).  The host hands the nodes
+ * over in pre-order, where a node's first inner child is its neighbour and the other three lie a whole subtree away.
+ *   policy 0: as given;
+ *   policy 1: sibling clusters — the inner children of a node lie side by side (<= 256 B), clusters in depth-first order;
+ *   policy 2: the same, a cluster of two or more starting on a 128-byte line (the gaps are dead records);
+ *   policy >= 4: treelets of `policy` nodes grown from their root by largest box area first (the subtree tops a ray is most
+ *                likely to visit together share lines), treelets in depth-first order.
+ * order[new] = old (-1: a dead record), newid[old] = new. */
+void node_layout(const crt_scene_desc* d, int policy, std::vector<int>& order, std::vector<int>& newid)
+{
+    const int n = d->num_nodes4;
+    order.clear(); newid.assign((size_t)n, -1);
+    if (n == 0) return;
+    if (policy <= 0) { order.resize((size_t)n); for (int i = 0; i < n; i++) { order[i] = i; newid[i] = i; } return; }
+    auto place = [&](int node) { newid[node] = (int)order.size(); order.push_back(node); };
+    if (policy < 4) {
+        std::vector<int> stack;
+        place(0); stack.push_back(0);
+        while (!stack.empty()) {
+            const int node = stack.back(); stack.pop_back();
+            const crt_bvh4_node& nd = d->nodes4[node];
+            int kids[4], nk = 0;
+            for (int c = 0; c < 4; c++) if (nd.type[c] == -1 && newid[nd.child[c]] < 0) {
+                bool dup = false;
+                for (int k = 0; k < nk; k++) dup = dup || kids[k] == nd.child[c];
+                if (!dup) kids[nk++] = nd.child[c];
+            }
+            if (policy == 2 && nk >= 2 && (order.size() & 1)) order.push_back(-1);
+            for (int k = 0; k < nk; k++) place(kids[k]);
+            for (int k = nk - 1; k >= 0; k--) stack.push_back(kids[k]);
+        }
+    } else {
+        struct Cand { float area; int node; bool operator<(const Cand& o) const { return area < o.area; } };
+        auto child_area = [&](const crt_bvh4_node& nd, int c) -> float {
+            const float ex = nd.bbox[12 + c] - nd.bbox[c], ey = nd.bbox[16 + c] - nd.bbox[4 + c], ez = nd.bbox[20 + c] - nd.bbox[8 + c];
+            const float a = ex * ey + ey * ez + ez * ex;
+            return a == a ? a : 0.0f;
+        };
+        std::vector<int> roots;                      /* treelet roots still to be laid out, depth-first */
+        roots.push_back(0);
+        std::vector<Cand> heap;
+        std::vector<int> spill;
+        while (!roots.empty()) {
+            const int root = roots.back(); roots.pop_back();
+            if (newid[root] >= 0) continue;
+            heap.clear();
+            heap.push_back(Cand{ 3.0e38f, root });
+            int placed = 0;
+            while (!heap.empty() && placed < policy) {
+                std::pop_heap(heap.begin(), heap.end());
+                const Cand c = heap.back(); heap.pop_back();
+                if (newid[c.node] >= 0) continue;
+                place(c.node); placed++;
+                const crt_bvh4_node& nd = d->nodes4[c.node];
+                for (int k = 0; k < 4; k++) if (nd.type[k] == -1 && newid[nd.child[k]] < 0) {
+                    heap.push_back(Cand{ child_area(nd, k), nd.child[k] });
+                    std::push_heap(heap.begin(), heap.end());
+                }
+            }
+            /* what is left on the frontier roots its own treelet; the largest is laid out next */
+            std::sort(heap.begin(), heap.end());
+            for (size_t k = 0; k < heap.size(); k++) roots.push_back(heap[k].node);
+        }
+    }
+    for (int i = 0; i < n; i++) if (newid[i] < 0) place(i);          /* not reachable from the root: kept, at the end */
+}
+
+/* Uniform grid: per cell the chessboard (Chebyshev) distance to the nearest cell that holds an object, 0 for a cell that holds
+ * one, capped at 255.  A 3D-DDA step changes one cell coordinate by one, so from a cell at distance d the next d - 1 cells of ANY
+ * ray are empty: k_grid steps through them without reading cell_start.  Two-pass chamfer over a volume padded by one cell (exact
+ * for this metric). */
+void grid_distance_field(const crt_scene_desc* d, std::vector<unsigned char>& out)
+{
+    const int nx = d->grid.nx, ny = d->grid.ny, nz = d->grid.nz;
+    const size_t px = (size_t)nx + 2, pz = (size_t)nz + 2, py = (size_t)ny + 2;
+    std::vector<unsigned char> v(px * py * pz, (unsigned char)255);
+    auto at = [&](int ix, int iy, int iz) -> size_t { return ((size_t)(iy + 1) * pz + (size_t)(iz + 1)) * px + (size_t)(ix + 1); };
+    for (int iy = 0; iy < ny; iy++) for (int iz = 0; iz < nz; iz++) for (int ix = 0; ix < nx; ix++) {
+        const size_t c = ((size_t)iy * nz + iz) * nx + ix;
+        if (d->cell_start[c + 1] > d->cell_start[c]) v[at(ix, iy, iz)] = 0;
+    }
+    ptrdiff_t before[13]; int nb = 0;             /* the 13 neighbours that precede a cell in scan order (y, then z, then x) */
+    for (int dy = -1; dy <= 1; dy++) for (int dz = -1; dz <= 1; dz++) for (int dx = -1; dx <= 1; dx++) {
+        const ptrdiff_t off = ((ptrdiff_t)dy * (ptrdiff_t)pz + dz) * (ptrdiff_t)px + dx;
+        if (off < 0) before[nb++] = off;
+    }
+    for (int iy = 0; iy < ny; iy++) for (int iz = 0; iz < nz; iz++) {
+        unsigned char* row = &v[at(0, iy, iz)];
+        for (int ix = 0; ix < nx; ix++) {
+            unsigned m = row[ix];
+            if (m == 0) continue;
+            for (int k = 0; k < 13; k++) { const unsigned q = (unsigned)row[ix + before[k]] + 1u; if (q < m) m = q; }
+            row[ix] = (unsigned char)m;
+        }
+    }
+    for (int iy = ny - 1; iy >= 0; iy--) for (int iz = nz - 1; iz >= 0; iz--) {
+        unsigned char* row = &v[at(0, iy, iz)];
+        for (int ix = nx - 1; ix >= 0; ix--) {
+            unsigned m = row[ix];
+            if (m == 0) continue;
+            for (int k = 0; k < 13; k++) { const unsigned q = (unsigned)row[ix - before[k]] + 1u; if (q < m) m = q; }
+            row[ix] = (unsigned char)m;
+        }
+    }
+    out.resize((size_t)nx * ny * nz);
+    for (int iy = 0; iy < ny; iy++) for (int iz = 0; iz < nz; iz++)
+        memcpy(&out[((size_t)iy * nz + iz) * nx], &v[at(0, iy, iz)], (size_t)nx);
 }
 
 int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
@@ -217,7 +335,7 @@ int upload(void** dst, const std::vector<T>& v)
 void free_scene(crt_scene* s)
 {
     if (!s) return;
-    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items,
+    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist,
                      s->d_bnodes2, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
                      s->own.bin_hist, s->own.bin_cursor, s->own.perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -362,7 +480,8 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
     case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) return launch(s, k_bvh4_closest_tri<COUNT>, la, st, true, na);
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
-    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
+                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st, false, na);
     default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, false, na);
@@ -375,7 +494,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, true);
                          return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
-    case CRT_ACCEL_BVH:  return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, true);
+                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
     default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
@@ -481,17 +601,27 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         /* the reference-control-flow QBVH walk adds one frame marker per tree level to the stack */
         if (desc->accel == CRT_ACCEL_BVH4 && !accel_bounded && CRT_STACK_PER_LEVEL_EXACT * d4 + 1 > CRT_STACK_MAX) { free_scene(s); return CRT_E_TOOBIG; }
 
+        std::vector<int> order, newid;
+        if (desc->accel == CRT_ACCEL_BVH4) {
+            const char* e = getenv("CRT_NODE_ORDER");
+            node_layout(desc, e ? atoi(e) : CRT_NODE_ORDER_DEFAULT, order, newid);
+            if (order.size() > (size_t)CRT_NODE_MASK) { free_scene(s); return CRT_E_TOOBIG; }
+        }
+        const int num_slots = (int)order.size();
+        auto child_word = [&](const crt_bvh4_node& nd, int c) -> unsigned {      /* an inner word carries the child's own axis2: known at pop, no load */
+            return nd.type[c] == -1 ? (((unsigned)(desc->nodes4[nd.child[c]].axis & 0x03) << 28) | (unsigned)newid[nd.child[c]])
+                                    : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
+        };
         std::vector<float4> n4;
         if (desc->accel == CRT_ACCEL_BVH4) {
-            n4.resize((size_t)desc->num_nodes4 * 8);
-            for (int i = 0; i < desc->num_nodes4; i++) {
-                const crt_bvh4_node& nd = desc->nodes4[i];
+            n4.assign((size_t)num_slots * 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            for (int i = 0; i < num_slots; i++) {
+                if (order[i] < 0) continue;
+                const crt_bvh4_node& nd = desc->nodes4[order[i]];
                 float4* q = &n4[(size_t)i * 8];
                 for (int k = 0; k < 6; k++) q[k] = make_float4(nd.bbox[4*k], nd.bbox[4*k+1], nd.bbox[4*k+2], nd.bbox[4*k+3]);
                 unsigned w[4];
-                for (int c = 0; c < 4; c++)       /* an inner word carries the child's own axis2: known at pop, no load */
-                    w[c] = nd.type[c] == -1 ? (((unsigned)(desc->nodes4[nd.child[c]].axis & 0x03) << 28) | (unsigned)nd.child[c])
-                                            : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
+                for (int c = 0; c < 4; c++) w[c] = child_word(nd, c);
                 float wf[4]; memcpy(wf, w, 16);
                 q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
                 int ax2 = nd.axis & 0x03;                          /* bvh4.h:308 */
@@ -504,9 +634,10 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         std::vector<uint32_t> cn4;
         bool cn_ok = desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0;
         if (cn_ok) {
-            cn4.assign((size_t)desc->num_nodes4 * 16, 0u);
-            for (int i = 0; i < desc->num_nodes4 && cn_ok; i++) {
-                const crt_bvh4_node& nd = desc->nodes4[i];
+            cn4.assign((size_t)num_slots * 16, 0u);
+            for (int i = 0; i < num_slots && cn_ok; i++) {
+                if (order[i] < 0) continue;
+                const crt_bvh4_node& nd = desc->nodes4[order[i]];
                 float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
                 bool valid[4], any = false;
                 for (int c = 0; c < 4; c++) {
@@ -552,9 +683,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                     }
                     q[6 + k] = lo_word; q[9 + k] = hi_word;
                 }
-                for (int c = 0; c < 4; c++)
-                    q[12 + c] = nd.type[c] == -1 ? (((unsigned)(desc->nodes4[nd.child[c]].axis & 0x03) << 28) | (unsigned)nd.child[c])
-                                                 : (CRT_LEAF_BIT | ((unsigned)nd.type[c] << 28) | (unsigned)nd.child[c]);
+                for (int c = 0; c < 4; c++) q[12 + c] = child_word(nd, c);
             }
             if (!cn_ok) cn4.clear();
         }
@@ -596,19 +725,37 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 q[3] = make_float4(lf, rf, 0.0f, 0.0f);
             }
             s->root_word2 = word(0);
+            {   /* leaves in left-first depth-first order: strictly increasing object index? */
+                std::vector<int> stack;
+                stack.push_back(0);
+                int last = -1;
+                bool inc = true;
+                while (!stack.empty() && inc) {
+                    const int node = stack.back(); stack.pop_back();
+                    const crt_bvh2_node& c = desc->nodes2[node];
+                    if (c.left < 0) { inc = c.right > last; last = c.right; }
+                    else { stack.push_back(c.right); stack.push_back(c.left); }
+                }
+                const char* e = getenv("CRT_BVH2_ORDERED");
+                s->bvh2_ordered = inc && !(e && atoi(e) == 0);
+            }
             for (int a = 0; a < 3; a++) { s->dev.root_bmin[a] = desc->nodes2[0].bmin[a]; s->dev.root_bmax[a] = desc->nodes2[0].bmax[a]; }
         }
         std::vector<crt_shape> shapes;
         if (desc->num_shapes > 0) shapes.assign(desc->shapes, desc->shapes + desc->num_shapes);
         std::vector<int32_t> cs, ci;
+        std::vector<unsigned char> cd;
         if (desc->accel == CRT_ACCEL_GRID) {
             cs.assign(desc->cell_start, desc->cell_start + desc->grid.num_cells + 1);
             if (cs.back() > 0) ci.assign(desc->cell_items, desc->cell_items + cs.back());
+            grid_distance_field(desc, cd);
+            const char* e = getenv("CRT_GRID_SKIP");                      /* A/B knob: 0 = no cell is skipped, as the reference walks */
+            if (e && atoi(e) == 0) for (size_t c = 0; c < cd.size(); c++) if (cd[c] > 1) cd[c] = 1;
         }
-
         if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK ||
             (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
-            (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK) {
+            (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK ||
+            (rc = upload(&s->d_cell_dist, cd)) != CRT_OK) {
             free_scene(s);
             return rc;
         }
@@ -654,6 +801,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.shapes = (const crt_shape*)s->d_shapes;
     dv.nodes2 = (const float4*)s->d_nodes2;
     dv.cell_start = (const int*)s->d_cell_start;
+    dv.cell_dist = (const unsigned char*)s->d_cell_dist;
     dv.cell_items = (const int*)s->d_cell_items;
     dv.counters = s->d_counters;
     dv.grid = desc->grid;

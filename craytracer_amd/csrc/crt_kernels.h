@@ -1094,7 +1094,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
 /* EXACT = BVHIntersectTest / BVHShadowIntersectTest as written (intersect.h:310-362): every
  * box-overlapped subtree is walked, nothing is culled by t; `t1 < t2 ? left : right` at every level
  * makes the LAST of equal hits in left-first order win, which is the `<=` below. */
-template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false>
+/* ORDERED (pruned mode only, and only when the host has checked that left-first depth-first order meets the leaves in
+ * increasing object index — the reference's in-place builder gives that): the nearer child is walked first, so best t
+ * tightens early and far subtrees fall to the pruning test.  The reference's answer is a function of the SET of
+ * reachable hits, not of the walk: least t, and among equal t the last in left-first order = the largest object index;
+ * the update rule below says exactly that, whatever the order the hits are met in.  A subtree is still skipped only when its
+ * entry t lies strictly beyond best t, so no hit of equal t is ever lost. */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false, bool ORDERED = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
@@ -1114,6 +1120,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
     float best_t = CRT_TMAX;
+    unsigned best_idx = 0;
     DHit best; best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
 
     RayFeed<false> feed;
@@ -1125,6 +1132,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
             if (feed.take(la, idle, !alive, &ri, &ray, &unused_ld)) {
                 ia = 1.0f / ray.dx; ib = 1.0f / ray.dy; ic = 1.0f / ray.dz;           /* aabb.cpp:94,:106,:118 */
                 best_t = CRT_TMAX;
+                best_idx = 0;
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
                 st.sp = 0;
                 cur = sc.root_word;
@@ -1146,6 +1154,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                     const float t = dev_object<TRI_ONLY>(sc, (int)(cur & ~CRT_LEAF_BIT), ray, SHADOW, &h);
                     if (COUNT) c_prims++;
                     if (SHADOW) { if (t < best_t) best_t = t; }
+                    else if (ORDERED) {
+                        const unsigned idx = cur & ~CRT_LEAF_BIT;
+                        if (t < CRT_TMAX && (t < best_t || (t == best_t && idx > best_idx))) { best_t = t; best = h; best_idx = idx; }
+                    }
                     else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
                 } else {
                     const float4* nd = sc.bnodes2 + (size_t)cur * 4;
@@ -1161,7 +1173,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                     const bool lv = lbt < CRT_TMAX && (EXACT || !(lkey > best_t));
                     const bool rv = rbt < CRT_TMAX && (EXACT || !(rkey > best_t));
                     const unsigned lw = __float_as_uint(q3.x), rw = __float_as_uint(q3.y);
-                    if (lv) {
+                    if (ORDERED && lv && rv) {
+                        const bool right_first = rkey < lkey;
+                        st.push(right_first ? lw : rw, right_first ? lkey : rkey);
+                        cur = right_first ? rw : lw; need_pop = false;
+                    } else if (lv) {
                         if (rv) st.push(rw, rkey);
                         cur = lw; need_pop = false;
                     } else if (rv) { cur = rw; need_pop = false; }
@@ -1269,6 +1285,16 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
             if (w.hits) {
                 while (w.ix != w.ex && w.iy != w.ey && w.iz != w.ez) {
                     const int cell = w.iy * sc.grid.nz * sc.grid.nx + w.iz * sc.grid.nx + w.ix;
+                    /* an empty cell only steps (its obj_t is TMAX, intersect.h:152 never accepts): the distance field says how many
+                     * cells from here are empty whatever the direction, and those are stepped through without a fetch */
+                    unsigned skip = sc.cell_dist[cell];
+                    if (skip != 0u) {
+                        do {
+                            if (COUNT) c_nodes++;
+                            grid_step(&w);
+                        } while (--skip != 0u && w.ix != w.ex && w.iy != w.ey && w.iz != w.ez);
+                        continue;
+                    }
                     const int cb = sc.cell_start[cell], ce = sc.cell_start[cell + 1];
                     if (COUNT) c_nodes++;
                     if (!SHADOW) {

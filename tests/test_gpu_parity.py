@@ -239,3 +239,48 @@ def test_sah_tree_of_instanced_shapes_is_accepted_and_walked():
     assert (w["obj"] >= 0).mean() > 0.25
     assert np.array_equal(g["obj"], w["obj"]) and close(g["t"], w["t"]).all()
     sc.close()
+
+
+def _tie_scene():
+    """Every triangle three times over (shuffled): each hit is an exact-t tie of three objects, so the answer shows
+    which of them the walk's tie rule picks."""
+    v = scenes.random_tris(1500, seed=12, size=0.08).tri_verts
+    v = np.concatenate([v, v, v])
+    rng = np.random.Generator(np.random.PCG64(4))
+    return api.SceneInput(v[rng.permutation(len(v))])
+
+
+@pytest.mark.parametrize("scene", ["blobs", "ties"])
+def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
+    """The device-side choices the host makes at scene creation -- node order in memory (QBVH), nearer-child-first pruned
+    walk (binary BVH), empty-cell skipping by distance field (grid) -- are invisible in the results: each is switched
+    through its environment knob and compared bit for bit with the other setting and with the oracle, on a scene whose
+    every hit is a three-way exact tie as well."""
+    si = scenes.courtyard(4, 16, 32, seed=5) if scene == "blobs" else _tie_scene()
+    rays, ld = rayset(si, 8192, 21)
+    for accel, knob, settings in ((api.ACCEL_BVH4, "CRT_NODE_ORDER", ("0", "1", "2", "8")),
+                                  (api.ACCEL_BVH, "CRT_BVH2_ORDERED", ("0", "1")),
+                                  (api.ACCEL_GRID, "CRT_GRID_SKIP", ("0", "1"))):
+        built = api.BuiltScene(si, accel)
+        o = ol.OracleScene(si, accel, sort_mode=0)
+        o_hits = o.intersect(rays, mode=api.TRAVERSE_EXACT)
+        o_t, o_occ = o.shadow(rays, ld)
+        cells = []
+        for val in settings:
+            monkeypatch.setenv(knob, val)
+            sc = api.Scene(built, 0)                      # the knob is read here
+            sc.enable_counters(True)
+            sc.reset_counters()
+            g_hits = sc.intersect(rays)
+            cells.append(sc.counters()["nodes_visited"])
+            g_t, g_occ = sc.shadow(rays, ld)
+            sc.close()
+            assert ol.same_bits(g_hits, o_hits), (accel, knob, val)
+            assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ), (accel, knob, val)
+        monkeypatch.delenv(knob)
+        if accel == api.ACCEL_GRID:                       # skipped cells are still counted as walked
+            assert cells[0] == cells[1]
+        if accel == api.ACCEL_BVH4:                       # the same walk whatever the addresses
+            assert len(set(cells)) == 1
+        if accel == api.ACCEL_BVH and scene == "blobs":   # nearer child first tests fewer boxes
+            assert cells[1] < cells[0]
