@@ -413,11 +413,14 @@ const size_t CRT_PERM_PRESIZE = (size_t)1 << 24;      /* 64 MB: ray order for ba
 #define CRT_MAX_BLOCKS 5
 #endif
 const int CRT_MAX_BLOCKS_PER_CU = CRT_MAX_BLOCKS;
+#ifndef CRT_GRID_BLOCKS
+#define CRT_GRID_BLOCKS 8          /* the grid walk has no LDS stack and waits on dependent fetches: all the waves its registers allow */
+#endif
 
 /* NOALLOC: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
  * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before. */
 template <class K>
-int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false, bool noalloc = false)
+int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false, bool noalloc = false, int max_blocks = CRT_MAX_BLOCKS_PER_CU)
 {
     std::lock_guard<std::mutex> lock(s->mu);
     Scratch& sx = noalloc ? s->na : s->own;
@@ -428,7 +431,7 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
         if (per_cu < 1) per_cu = 1;
         if (s->n_occ < CRT_OCC_CACHE) { s->occ[s->n_occ].fn = (const void*)kernel; s->occ[s->n_occ].per_cu = per_cu; s->n_occ++; }
     }
-    if (per_cu > CRT_MAX_BLOCKS_PER_CU) per_cu = CRT_MAX_BLOCKS_PER_CU;
+    if (per_cu > max_blocks) per_cu = max_blocks;
     unsigned blocks = (unsigned)(s->num_cus * per_cu);
     unsigned need = (la.n + CRT_BLOCK - 1) / CRT_BLOCK;
     if (blocks > need) blocks = need;
@@ -483,7 +486,7 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
     case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
-    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st, false, na);
+    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, false>, la, st, true, na, CRT_GRID_BLOCKS);
     default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, false, na);
     }
 }
@@ -497,7 +500,7 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, true);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
-    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st);
+    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st, true, false, CRT_GRID_BLOCKS);
     default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
     }
 }
@@ -596,6 +599,16 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 }
                 s->bin_grid_valid = true;
             }
+        }
+        if (desc->accel == CRT_ACCEL_GRID && desc->grid.num_cells > 0) {       /* the grid's own box */
+            bool ok = true;
+            for (int a = 0; a < 3; a++) {
+                const float lo = desc->grid.bmin[a], ext = desc->grid.bmax[a] - desc->grid.bmin[a];
+                if (!(fabsf(lo) < 1.0e30f) || !(ext < 1.0e30f)) ok = false;
+                s->bin_grid.lo[a] = lo;
+                s->bin_grid.scale[a] = ext > 0.0f ? (float)(1 << CRT_BIN_BITS) / ext : 0.0f;
+            }
+            s->bin_grid_valid = ok;
         }
         s->binning = true;
         /* the reference-control-flow QBVH walk adds one frame marker per tree level to the stack */

@@ -1272,8 +1272,9 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
     for (;;) {
         const unsigned base = next_batch(la.queue_head);
         if (base >= la.n) break;
-        const unsigned ri = base + lane;
-        if (ri < la.n) {
+        const unsigned slot = base + lane;
+        if (slot < la.n) {
+            const unsigned ri = la.perm ? la.perm[slot] : slot;                       /* binned batches: neighbours in space walk together */
             const DRay ray = load_ray(la.rays, ri);
             const float ld = SHADOW ? la.light_dist[ri] : 0.0f;
             const float bound = ld - CRT_K_EPSILON;                                    /* intersect.h:276 */
