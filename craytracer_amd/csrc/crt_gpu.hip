@@ -1128,6 +1128,8 @@ int crt_scene_get_counters(crt_scene* s, crt_counters* out)
         fprintf(stderr, "\n");
         fprintf(stderr, "[diag] wave-iterations %llu  alive/it %.2f  walking/it %.2f  node lanes/it %.2f  object lanes/it %.2f  stalled/it %.2f  iterations with a node step %.3f  with an object step %.3f\n",
                 d[0], (double)d[1] / d[0], (double)d[8] / d[0], (double)d[2] / d[0], (double)d[3] / d[0], (double)d[5] / d[0], (double)d[6] / d[0], (double)d[7] / d[0]);
+        fprintf(stderr, "[diag] node-step iterations whose lanes all visit one node: %.4f of them; distinct nodes per node-step iteration %.2f\n",
+                d[6] ? (double)d[9] / d[6] : 0.0, d[6] ? (double)d[10] / d[6] : 0.0);
     }
 #endif
     return CRT_OK;

@@ -665,7 +665,8 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
 #if CRT_DIAG
     unsigned d_it = 0, d_alive = 0, d_node = 0, d_obj = 0, d_pop = 0, d_stall = 0, d_nodeit = 0, d_objit = 0, d_walk = 0;
     unsigned d_ray_it = 0;        /* iterations the lane's current ray has been in flight */
-    unsigned d_tail_it = 0, d_tail_alive = 0, d_steals = 0, d_tail_max = 0;
+    unsigned d_tail_it = 0, d_tail_alive = 0, d_steals = 0;
+    unsigned d_uniform = 0, d_distinct = 0;      /* node-step iterations whose lanes all visit ONE node; distinct nodes per node-step iteration, summed */
 #endif
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
@@ -772,6 +773,16 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
             d_stall += (unsigned)__popcll(__ballot(leafcur && plbusy));
             d_walk += (unsigned)__popcll(__ballot(alive && walking));
             d_nodeit += n_in ? 1u : 0u; d_objit += n_ob ? 1u : 0u;
+            {
+                unsigned long long left = __ballot(inner);
+                unsigned distinct = 0;
+                while (left) {
+                    const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)cur, (int)__builtin_ctzll(left));
+                    left &= ~__ballot(inner && cur == v);
+                    distinct++;
+                }
+                d_distinct += distinct; d_uniform += distinct == 1u ? 1u : 0u;
+            }
         }
 #endif
         if (alive) {
@@ -871,6 +882,8 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
         atomicAdd(&sc.counters[5], (unsigned long long)d_tail_alive);
         atomicAdd(&sc.counters[6], (unsigned long long)d_steals);
         atomicMax(&sc.counters[7], (unsigned long long)d_tail_it);
+        atomicAdd(&sc.counters[17], (unsigned long long)d_uniform);
+        atomicAdd(&sc.counters[18], (unsigned long long)d_distinct);
     }
 #endif
 }
