@@ -1351,3 +1351,116 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
     }
     flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
 }
+
+/* The same walk with lane refill (round 2; closest hit, triangle-only scenes).  The plain kernel above keeps 64 rays per wave until
+ * the longest is done; its counters say 7 % of the lanes are active per VALU instruction -- the rays' walks differ in length by orders of magnitude and each step
+ * of a walk is short.  Here a lane holds one ray and does ONE thing per wave iteration:
+ *   - at a cell it has not looked at: range check, the distance byte; an empty cell -> up to CRT_GRID_SKIP_STEPS DDA steps (what
+ *     is left of the distance is carried over), an occupied one -> its item range;
+ *   - inside an occupied cell: one object test; after the cell's last object the accept test of intersect.h:152 and a DDA step;
+ *   - finished: the non-grid objects, the store, and the lane is idle until the feed hands it the next ray.
+ * Cells, objects and their order per ray are exactly those of the loop above. */
+#ifndef CRT_GRID_SKIP_STEPS
+#define CRT_GRID_SKIP_STEPS 4
+#endif
+#ifndef CRT_GRID_REFILL_MIN
+#define CRT_GRID_REFILL_MIN 16
+#endif
+template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+__global__ __launch_bounds__(CRT_BLOCK) void k_grid_refill(DevScene sc, LaunchArgs la)
+{
+    resolve_count(la);
+    unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
+    bool alive = false;
+    unsigned ri = 0;
+    DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
+    float ld = 0.0f, bound = 0.0f;
+    GridWalk w; w.hits = false; w.ix = w.iy = w.iz = 0; w.sx = w.sy = w.sz = 1; w.ex = w.ey = w.ez = 0;
+    w.tx = w.ty = w.tz = 0.0f; w.dtx = w.dty = w.dtz = 0.0f;
+    int k = 0, ce = 0;                  /* objects of the current cell still to test: cell_items[k .. ce) */
+    int item = 0;                       /* cell_items[k], fetched one iteration ahead so that an object step waits for one fetch, not two */
+    unsigned skip_left = 0;             /* empty cells ahead that need no look */
+    float obj_t = CRT_TMAX;             /* nearest hit among the current cell's objects (closest) / the accepted t */
+    DHit obj_h; obj_h.obj = -1; obj_h.part = -1; obj_h.beta = 0.0f; obj_h.gamma = 0.0f;
+    bool found = false;                 /* the grid walk ended with a hit (closest: accepted; shadow: below the bound) */
+
+    RayFeed<SHADOW> feed;
+    feed.start(la);
+    for (;;) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_GRID_REFILL_MIN) {
+            if (feed.take(la, idle, !alive, &ri, &ray, &ld)) {
+                bound = ld - CRT_K_EPSILON;                                            /* intersect.h:276 */
+                grid_setup(sc, ray, &w);
+                k = ce = 0; skip_left = 0;
+                obj_t = CRT_TMAX; obj_h.obj = -1; obj_h.part = -1; obj_h.beta = 0.0f; obj_h.gamma = 0.0f;
+                found = false;
+                alive = true;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive) {
+            bool finish = !w.hits;
+            if (!finish) {
+                if (k < ce) {
+                    DHit h;
+                    const int cur_item = item;
+                    k++;
+                    if (k < ce) item = sc.cell_items[k];
+                    const float tt = dev_object<TRI_ONLY>(sc, cur_item, ray, SHADOW, &h);
+                    if (COUNT) c_prims++;
+                    if (!SHADOW) {
+                        if (tt < obj_t) { obj_t = tt; obj_h = h; }
+                        if (k == ce) {
+                            if (rmin(obj_t, rmin(w.tx, rmin(w.ty, w.tz))) == obj_t && obj_t < CRT_TMAX) { found = true; finish = true; }   /* intersect.h:152 */
+                            else { obj_t = CRT_TMAX; obj_h.obj = -1; obj_h.part = -1; obj_h.beta = 0.0f; obj_h.gamma = 0.0f; grid_step(&w); }
+                        }
+                    } else {
+                        if (tt < bound) { obj_t = tt; found = true; finish = true; }
+                        else if (k == ce) grid_step(&w);
+                    }
+                } else if (!(w.ix != w.ex && w.iy != w.ey && w.iz != w.ez)) {
+                    finish = true;
+                } else {
+                    if (skip_left == 0u) {
+                        const int cell = w.iy * sc.grid.nz * sc.grid.nx + w.iz * sc.grid.nx + w.ix;
+                        skip_left = sc.cell_dist[cell];
+                        if (skip_left == 0u) {
+                            k = sc.cell_start[cell]; ce = sc.cell_start[cell + 1];
+                            item = sc.cell_items[k];
+                            if (COUNT) c_nodes++;
+                        }
+                    }
+                    if (skip_left != 0u) {
+                        unsigned steps = skip_left < (unsigned)CRT_GRID_SKIP_STEPS ? skip_left : (unsigned)CRT_GRID_SKIP_STEPS;
+                        do {
+                            if (COUNT) c_nodes++;
+                            grid_step(&w);
+                            skip_left--;
+                        } while (--steps != 0u && w.ix != w.ex && w.iy != w.ey && w.iz != w.ez);
+                    }
+                }
+            }
+            if (finish) {
+                if (!SHADOW) {
+                    float t = found ? obj_t : CRT_TMAX;
+                    DHit best = obj_h;
+                    if (!found) { best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f; }
+                    float min_t = CRT_TMAX;
+                    DHit mh = best;
+                    linear_closest<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, &min_t, &mh, &c_prims);   /* intersect.h:177-192 */
+                    if (min_t < t) { best = mh; t = min_t; }
+                    store_hit(la.hits, ri, t, best);
+                } else {
+                    float t = found ? obj_t : CRT_TMAX;
+                    if (!found) t = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, bound, CRT_TMAX, &c_prims);  /* :298-307 */
+                    if (la.t_out) la.t_out[ri] = t;
+                    if (la.occ_out) la.occ_out[ri] = (t < ld - CRT_K_EPSILON) ? 1 : 0;
+                }
+                if (COUNT) c_rays++;
+                alive = false;
+            }
+        }
+    }
+    flush_counters<COUNT>(sc, c_rays, c_nodes, c_prims, SHADOW);
+}
