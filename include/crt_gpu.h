@@ -214,7 +214,7 @@ int  crt_scene_get_traverse_mode(const crt_scene* s, int* resolved_mode);
 int  crt_host_alloc(size_t bytes, void** out);
 void crt_host_free(void* p);
 
-/* Ray binning (on by default).  No counterpart in the reference.  For QBVH scenes and batches of
+/* Ray binning (on by default).  No counterpart in the reference.  For QBVH, binary-BVH and grid scenes and batches of
  * 2^18 rays or more, the library first counting-sorts the ray INDICES by the grid cell of the ray
  * origin and pulls rays from the queue in that order (better L2 reuse); every ray is traced
  * exactly as before and its result is written at its own index, so outputs do not change. */
