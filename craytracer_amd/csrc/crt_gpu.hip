@@ -72,6 +72,7 @@ struct crt_scene {
     bool count;
     bool compress;            /* walk the 64-byte conservative copy of the QBVH nodes where that is allowed (see crt_scene_set_node_compression) */
     bool cnodes_valid;        /* the copy exists (every node box was finite) */
+    unsigned split_max_rays;  /* closest-hit batches up to this many rays take the tail-splitting walk */
     bool bvh2_ordered;        /* binary BVH: left-first depth-first order meets the leaves in increasing object index, so the pruned
                                  walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
@@ -97,6 +98,9 @@ struct crt_scene {
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
 
+#ifndef CRT_SPLIT_MAX_RAYS_DEFAULT
+#define CRT_SPLIT_MAX_RAYS_DEFAULT (1u << 23)     /* +18 % at 2^20 rays, +12 % at 2^21, +7 % at 2^22, +3 % at 2^23, -1 % at 2^24 */
+#endif
 #ifndef CRT_NODE_ORDER_DEFAULT
 #define CRT_NODE_ORDER_DEFAULT 1
 #endif
@@ -480,7 +484,13 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) return launch(s, k_bvh4_closest_tri<COUNT>, la, st, true, na);
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) {
+                             /* small batches: the walk whose idle lanes take pending subtrees from busy ones once the queue is dry
+                              * (crt_kernels.h, "tail splitting").  Not for counted launches (n is an upper bound there) nor for the
+                              * no-allocation entry point (its overflow area is sized for the 14-entry LDS stack). */
+                             if (!na && !la.n_dev && la.n <= s->split_max_rays) return launch(s, k_bvh4_closest_tri<COUNT, true>, la, st, true, na);
+                             return launch(s, k_bvh4_closest_tri<COUNT>, la, st, true, na);
+                         }
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
     case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
@@ -704,6 +714,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             if (!cn_ok) cn4.clear();
         }
         s->cnodes_valid = cn_ok;
+        { const char* e = getenv("CRT_TAIL_SPLIT_MAX"); s->split_max_rays = e ? (unsigned)strtoul(e, 0, 10) : CRT_SPLIT_MAX_RAYS_DEFAULT; }
         s->compress = true;
 
         std::vector<float4> n2;
@@ -784,7 +795,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     if (!hip_ok(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute")) { free_scene(s); return CRT_E_HIP; }
     s->num_cus = cus > 0 ? cus : 1;
     s->own.ovf_threads = (unsigned)s->num_cus * 8u * CRT_BLOCK;       /* at most 8 resident 256-thread blocks per CU */
-    size_t ovf_bytes = (size_t)s->own.ovf_threads * CRT_OVF_DEPTH * sizeof(unsigned);
+    size_t ovf_bytes = (size_t)s->own.ovf_threads * (CRT_OVF_DEPTH + 1) * sizeof(unsigned);    /* + 1: the tail-splitting walk keeps one entry fewer in LDS */
     if (!hip_ok(hipMalloc((void**)&s->own.ovf_word, ovf_bytes), "hipMalloc") ||
         !hip_ok(hipMalloc((void**)&s->own.ovf_key, ovf_bytes), "hipMalloc") ||
         !hip_ok(hipMalloc((void**)&s->own.queue_head, 256), "hipMalloc") ||

@@ -67,19 +67,20 @@ __device__ __noinline__ StackEntry ovf_pop(const unsigned* ovf_word, const float
     return e;
 }
 
-struct LaneStack {
-    StackEntry (*lds)[CRT_BLOCK];   /* the workgroup's __shared__ [CRT_LDS_DEPTH][CRT_BLOCK] array */
+template <int DEPTH>
+struct LaneStackT {
+    StackEntry (*lds)[CRT_BLOCK];   /* the workgroup's __shared__ [DEPTH][CRT_BLOCK] array */
     unsigned* ovf_word;           /* &ovf_word[0][gtid] */
     float* ovf_key;
     unsigned ovf_stride;
     int sp;
     CRT_DEV void push(unsigned w, float key)
     {
-        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) {
+        if (__builtin_expect(sp < DEPTH, 1)) {
             StackEntry e; e.x = w; e.y = __float_as_uint(key);
             lds[sp][threadIdx.x] = e;
         } else if (sp < CRT_STACK_MAX) {
-            ovf_push(ovf_word, ovf_key, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride, w, key);
+            ovf_push(ovf_word, ovf_key, (size_t)(sp - DEPTH) * ovf_stride, w, key);
         }
         /* deeper than CRT_STACK_MAX cannot happen: crt_scene_create rejects such trees */
         sp++;
@@ -88,11 +89,12 @@ struct LaneStack {
     {
         sp--;
         StackEntry e;
-        if (__builtin_expect(sp < CRT_LDS_DEPTH, 1)) e = lds[sp][threadIdx.x];
-        else e = ovf_pop(ovf_word, ovf_key, (size_t)(sp - CRT_LDS_DEPTH) * ovf_stride);
+        if (__builtin_expect(sp < DEPTH, 1)) e = lds[sp][threadIdx.x];
+        else e = ovf_pop(ovf_word, ovf_key, (size_t)(sp - DEPTH) * ovf_stride);
         *w = e.x; *key = __uint_as_float(e.y);
     }
 };
+typedef LaneStackT<CRT_LDS_DEPTH> LaneStack;
 
 /* words only (any-hit walks need no key): 4-byte entries, half the LDS, more resident waves */
 __device__ __noinline__ void ovf_push32(unsigned* ovf_word, size_t o, unsigned w) { ovf_word[o] = w; }
@@ -497,19 +499,21 @@ struct RayFeed {
  * the marker (all of the node's children done) folds the node's result into the parent's:
  * `if (t < min_t) min_t = t` (bvh4.h:366-370).  The hit record that survives this chain of strict
  * comparisons is the first-found global minimum, which best_t / best track as in the pruned walk. */
-template <bool TRI_ONLY, bool COUNT, bool EXACT, bool COMPRESSED>
+template <bool TRI_ONLY, bool COUNT, bool EXACT, bool COMPRESSED, bool SPLIT = (CRT_TAIL_SPLIT != 0)>
 CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
     /* PENDING: the conservative-node walk keeps the leaf it is testing in a register of its own (`pl`) and walks on while
      * the leaf's remaining objects are tested, one per iteration, next to the node steps (see the loop below). */
     constexpr bool PENDING = COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF;
-    __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
+    constexpr bool STEAL = PENDING && SPLIT;
+    /* the tail-splitting instance gives one LDS stack entry (2 KB) per lane for its 4 KB of slots: 30 KB, still five per CU */
+    constexpr int LDS_D = STEAL ? CRT_LDS_DEPTH - 1 : CRT_LDS_DEPTH;
+    __shared__ StackEntry s_stack[LDS_D][CRT_BLOCK];
     /* tail splitting: one slot per lane, {(t bits, object) of the best hit of the ray's pieces; pieces pending | tie << 32} */
-    __shared__ unsigned long long s_slot[(COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF && CRT_TAIL_SPLIT) ? 2 : 1]
-                                        [(COMPRESSED && !EXACT && TRI_ONLY && CRT_PENDING_LEAF && CRT_TAIL_SPLIT) ? CRT_BLOCK : 1];
+    __shared__ unsigned long long s_slot[STEAL ? 2 : 1][STEAL ? CRT_BLOCK : 1];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
-    LaneStack st;
+    LaneStackT<LDS_D> st;
     st.lds = s_stack;
     st.ovf_word = la.ovf_word + gtid;
     st.ovf_key = la.ovf_key + gtid;
@@ -522,7 +526,6 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
     unsigned pl = 0;              /* PENDING: leaf word whose objects are being tested (count field 0 = none) */
     /* tail splitting (see the block at the top of the loop): bottom of this lane's stack (entries below were given away), the group
      * this lane's piece belongs to, and the final-order index of the best object found (what the pieces' results are merged on) */
-    constexpr bool STEAL = PENDING && CRT_TAIL_SPLIT;
     /* bit 0: piece of a split ray; bit 1: never split this ray (re-walk after a tie); bits 8..13: slot.  In a piece the best
      * object's final-order index rides in best.part (0 for every triangle, and written as 0); best.obj < 0 with best_t < TMAX
      * means the bound came from another piece. */
@@ -691,10 +694,10 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
         if (STEAL && feed.empty) {
             /* givers: at least two pending entries, all in LDS, the top one an inner node (a leaf is not worth a hand-over) */
 #if CRT_STEAL_BOTTOM
-            bool can_give = alive && !(grp & 2u) && st.sp > SBASE + 1 && SBASE < CRT_LDS_DEPTH;
+            bool can_give = alive && !(grp & 2u) && st.sp > SBASE + 1 && SBASE < LDS_D;
             if (can_give) can_give = !(s_stack[SBASE][threadIdx.x].x & CRT_LEAF_BIT);
 #else
-            bool can_give = alive && !(grp & 2u) && st.sp > 1 && st.sp <= CRT_LDS_DEPTH;
+            bool can_give = alive && !(grp & 2u) && st.sp > 1 && st.sp <= LDS_D;
             if (can_give) can_give = !(s_stack[st.sp - 1][threadIdx.x].x & CRT_LEAF_BIT);
 #endif
             const unsigned long long give_m = __ballot(can_give), idle_m = __ballot(!alive);
@@ -896,10 +899,10 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_closest(DevSc
 /* The headline kernel: triangle-only scene, pruned walk over the conservative nodes, pending leaf, tail splitting.  A kernel of
  * its own so that its register budget (five waves per SIMD: 96 VGPRs; the tail-splitting block would otherwise take it to 104
  * and the fifth wave is worth 8 %) does not bind the other instantiations of the body. */
-template <bool COUNT>
+template <bool COUNT, bool SPLIT = false>
 __global__ __launch_bounds__(CRT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bvh4_closest_tri(DevScene sc, LaunchArgs la)
 {
-    bvh4_closest_body<true, COUNT, false, true>(sc, la);
+    bvh4_closest_body<true, COUNT, false, true, SPLIT>(sc, la);
 }
 
 /* =====================================================================================

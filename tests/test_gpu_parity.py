@@ -253,12 +253,14 @@ def _tie_scene():
 @pytest.mark.parametrize("scene", ["blobs", "ties"])
 def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
     """The device-side choices the host makes at scene creation -- node order in memory (QBVH), nearer-child-first pruned
-    walk (binary BVH), empty-cell skipping by distance field (grid) -- are invisible in the results: each is switched
+    walk (binary BVH), empty-cell skipping by distance field (grid), the tail-splitting walk for small batches (QBVH) -- are
+    invisible in the results: each is switched
     through its environment knob and compared bit for bit with the other setting and with the oracle, on a scene whose
     every hit is a three-way exact tie as well."""
     si = scenes.courtyard(4, 16, 32, seed=5) if scene == "blobs" else _tie_scene()
     rays, ld = rayset(si, 8192, 21)
     for accel, knob, settings in ((api.ACCEL_BVH4, "CRT_NODE_ORDER", ("0", "1", "2", "8")),
+                                  (api.ACCEL_BVH4, "CRT_TAIL_SPLIT_MAX", ("0", "100000000")),
                                   (api.ACCEL_BVH, "CRT_BVH2_ORDERED", ("0", "1")),
                                   (api.ACCEL_GRID, "CRT_GRID_SKIP", ("0", "1"))):
         built = api.BuiltScene(si, accel)
@@ -266,6 +268,8 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
         o_hits = o.intersect(rays, mode=api.TRAVERSE_EXACT)
         o_t, o_occ = o.shadow(rays, ld)
         cells = []
+        if knob == "CRT_NODE_ORDER":                      # visit counts are compared below: the plain walk (which lane takes which
+            monkeypatch.setenv("CRT_TAIL_SPLIT_MAX", "0")  # subtree in the tail-splitting walk depends on timing, its counts vary)
         for val in settings:
             monkeypatch.setenv(knob, val)
             sc = api.Scene(built, 0)                      # the knob is read here
@@ -278,9 +282,10 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
             assert ol.same_bits(g_hits, o_hits), (accel, knob, val)
             assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ), (accel, knob, val)
         monkeypatch.delenv(knob)
+        monkeypatch.delenv("CRT_TAIL_SPLIT_MAX", raising=False)
         if accel == api.ACCEL_GRID:                       # skipped cells are still counted as walked
             assert cells[0] == cells[1]
-        if accel == api.ACCEL_BVH4:                       # the same walk whatever the addresses
+        if knob == "CRT_NODE_ORDER":                      # the same walk whatever the addresses
             assert len(set(cells)) == 1
         if accel == api.ACCEL_BVH and scene == "blobs":   # nearer child first tests fewer boxes
             assert cells[1] < cells[0]
