@@ -17,7 +17,7 @@
  * are resident per CU -- at 16 deep (32 KB) only four fit in the 160 KB, and the fifth wave per SIMD is worth 8 % (1 813 ->
  * 1 954 Mrays/s; 12 deep: 1 915, six waves at 80 VGPRs and 12 / 13 deep: 1 844 / 1 854).  4-byte entries (any-hit walks): 16 deep. */
 #ifndef CRT_LDS_DEPTH
-#define CRT_LDS_DEPTH  14          /* (13 when the headline kernel's 4 KB of tail-splitting slots are compiled in: 30 KB, still five per CU) */
+#define CRT_LDS_DEPTH  14          /* (13 in the tail-splitting instance of the headline kernel, whose slots take 4 KB: 30 KB, still five per CU) */
 #endif
 #ifndef CRT_LDS_DEPTH32
 #define CRT_LDS_DEPTH32 16
@@ -367,7 +367,7 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #define CRT_STEAL_BOTTOM 0
 #endif
 #ifndef CRT_TAIL_SPLIT
-#define CRT_TAIL_SPLIT 0          /* experiment, off: see "tail splitting" in k_bvh4_closest's loop and DESIGN.md (build with -DCRT_TAIL_SPLIT=1 -DCRT_LDS_DEPTH=13) */
+#define CRT_TAIL_SPLIT 0          /* default of the body's SPLIT parameter; the host picks k_bvh4_closest_tri<COUNT, true> per launch for small batches */
 #endif
 #ifndef CRT_PENDING_LEAF
 #define CRT_PENDING_LEAF 1
