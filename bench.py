@@ -278,7 +278,7 @@ def main():
                          "the same kernel, so per-kernel profile averages would mix the two trees)")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
     ap.add_argument("--render-spp", type=int, default=32, help="samples per pixel per GPU timed in the render leg")
-    ap.add_argument("--render-cpu-spp", type=int, default=24, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
+    ap.add_argument("--render-cpu-spp", type=int, default=48, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
                     help="closest = the headline metric; shadow = the secondary any-hit metric")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
