@@ -185,7 +185,6 @@ void node_layout(const crt_scene_desc* d, int policy, std::vector<int>& order, s
         std::vector<int> roots;                      /* treelet roots still to be laid out, depth-first */
         roots.push_back(0);
         std::vector<Cand> heap;
-        std::vector<int> spill;
         while (!roots.empty()) {
             const int root = roots.back(); roots.pop_back();
             if (newid[root] >= 0) continue;
