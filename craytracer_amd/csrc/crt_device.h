@@ -47,6 +47,8 @@ struct DevScene {
     int nng;                        /* num_non_grid_obj */
     int n_accel;                    /* num_obj - nng */
     int accel;
+    const float4* bnodes2w;         /* binary BVH collapsed two levels at a time: 128-byte records of up to four boxes (crt_gpu.hip) */
+    unsigned root_word_w;           /* its root in child-word form */
     unsigned root_word;             /* QBVH: axis2(root) << 28 | 0;  BVH: child-word form of the root */
     const float4* bnodes2;          /* BVH: 64-byte inner-node records for k_bvh2 (see crt_kernels.h) */
     float root_bmin[3], root_bmax[3];

@@ -77,7 +77,7 @@ struct crt_scene {
                                  walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_cell_start; void* d_cell_items; void* d_cell_dist;
+    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist;
     unsigned long long* d_counters;
     Scratch own;              /* allocated by crt_scene_create (perm may grow) */
     Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
@@ -94,6 +94,8 @@ struct crt_scene {
     size_t chunk_cap;         /* rays per chunk buffer */
     /* ray binning (crt_binning.h): triangle-only QBVH scenes, batches of at least CRT_BIN_MIN_RAYS */
     unsigned root_word2;      /* BVH: root in k_bvh2's child-word form */
+    unsigned root_word2w;     /* ... and in the collapsed (four-box) records */
+    bool bvh2_wide;           /* the collapsed records exist and the ordered walk may use them */
     bool binning; BinGrid bin_grid; bool bin_grid_valid;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
@@ -339,7 +341,7 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist,
-                     s->d_bnodes2, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
+                     s->d_bnodes2, s->d_bnodes2w, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
                      s->own.bin_hist, s->own.bin_cursor, s->own.perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
@@ -492,7 +494,8 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na
                          }
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true>, la, st, true, na);
+                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
     case CRT_ACCEL_GRID: /* lane refill pays for incoherent closest-hit rays through triangles (735 -> 1 229 Mrays/s); the any-hit walk
@@ -509,7 +512,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, true);
                          return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, true);
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true>, la, st, true);
+                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, true);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
     case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st, true, false, CRT_GRID_BLOCKS);
@@ -727,7 +731,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             }
         }
         /* k_bvh2's layout: inner nodes only, renumbered in index order, each with both child boxes */
-        std::vector<float4> b2;
+        std::vector<float4> b2, b2w;
         if (desc->accel == CRT_ACCEL_BVH && desc->num_nodes2 > 0) {
             std::vector<int> inner_id((size_t)desc->num_nodes2, -1);
             int n_inner = 0;
@@ -765,6 +769,59 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 const char* e = getenv("CRT_BVH2_ORDERED");
                 s->bvh2_ordered = inc && !(e && atoi(e) == 0);
             }
+            /* Two levels at a time: a record per binary inner node at every other level, holding the boxes of its (up to four)
+             * grandchildren -- a child that is a leaf takes one slot itself.  The intermediate child's own box is then never tested;
+             * that changes nothing for a ray without NaN in its slab arithmetic, because a box that contains another passes the
+             * reference's test whenever the inner one does (subtraction and multiplication by one factor are monotone), and the
+             * containment is checked here.  Half the dependent steps per ray. */
+            {
+                const char* e = getenv("CRT_BVH2_WIDE");
+                bool ok = s->bvh2_ordered && !(e && atoi(e) == 0) && desc->nodes2[0].left >= 0 && 3 * ((d2 + 1) / 2) + 1 <= CRT_STACK_MAX;
+                std::vector<int> rec_of((size_t)desc->num_nodes2, -1), rec_nodes;
+                if (ok) { rec_of[0] = 0; rec_nodes.push_back(0); }
+                auto inside = [&](int c, int p) -> bool {
+                    const crt_bvh2_node& a = desc->nodes2[c]; const crt_bvh2_node& b = desc->nodes2[p];
+                    for (int k = 0; k < 3; k++) if (!(a.bmin[k] >= b.bmin[k] && a.bmax[k] <= b.bmax[k])) return false;
+                    return true;
+                };
+                for (size_t r = 0; ok && r < rec_nodes.size(); r++) {
+                    const int node = rec_nodes[r];
+                    const crt_bvh2_node& nd = desc->nodes2[node];
+                    int slots[4], ns = 0;
+                    const int kids[2] = { nd.left, nd.right };
+                    for (int k = 0; k < 2 && ok; k++) {
+                        const crt_bvh2_node& c = desc->nodes2[kids[k]];
+                        if (c.left < 0) slots[ns++] = kids[k];
+                        else {
+                            ok = inside(c.left, kids[k]) && inside(c.right, kids[k]);
+                            slots[ns++] = c.left; slots[ns++] = c.right;
+                        }
+                    }
+                    if (!ok) break;
+                    b2w.resize((r + 1) * 8);
+                    float bx[6][4]; unsigned wd[4];
+                    for (int c = 0; c < 4; c++) {
+                        for (int k = 0; k < 3; k++) { bx[k][c] = CRT_TMAX; bx[3 + k][c] = -CRT_TMAX; }     /* empty slot: never hit */
+                        wd[c] = 0xFFFFFFFFu;
+                        if (c >= ns) continue;
+                        const crt_bvh2_node& sn = desc->nodes2[slots[c]];
+                        for (int k = 0; k < 3; k++) { bx[k][c] = sn.bmin[k]; bx[3 + k][c] = sn.bmax[k]; }
+                        if (sn.left < 0) wd[c] = CRT_LEAF_BIT | (unsigned)sn.right;
+                        else {
+                            if (rec_of[slots[c]] < 0) { rec_of[slots[c]] = (int)rec_nodes.size(); rec_nodes.push_back(slots[c]); }
+                            wd[c] = (unsigned)rec_of[slots[c]];
+                        }
+                    }
+                    float4* q = &b2w[r * 8];
+                    for (int k = 0; k < 6; k++) q[k] = make_float4(bx[k][0], bx[k][1], bx[k][2], bx[k][3]);
+                    float wf[4]; memcpy(wf, wd, 16);
+                    q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
+                    q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                if (!ok) b2w.clear();
+                s->bvh2_wide = ok;
+                s->root_word2w = 0u;
+            }
             for (int a = 0; a < 3; a++) { s->dev.root_bmin[a] = desc->nodes2[0].bmin[a]; s->dev.root_bmax[a] = desc->nodes2[0].bmax[a]; }
         }
         std::vector<crt_shape> shapes;
@@ -779,7 +836,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             if (e && atoi(e) == 0) for (size_t c = 0; c < cd.size(); c++) if (cd[c] > 1) cd[c] = 1;
         }
         if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK ||
-            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
+            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_bnodes2w, b2w)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK ||
             (rc = upload(&s->d_cell_dist, cd)) != CRT_OK) {
             free_scene(s);
@@ -834,6 +891,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.num_obj = n; dv.nng = nng; dv.n_accel = n - nng; dv.accel = desc->accel;
     dv.root_word = (desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0) ? ((unsigned)(desc->nodes4[0].axis & 0x03) << 28) : 0u;
     if (desc->accel == CRT_ACCEL_BVH) dv.root_word = s->root_word2;
+    dv.bnodes2w = (const float4*)s->d_bnodes2w;
+    dv.root_word_w = s->root_word2w;
     dv.bnodes2 = (const float4*)s->d_bnodes2;
     *out = s;
     return CRT_OK;

@@ -1116,7 +1116,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
  * reachable hits, not of the walk: least t, and among equal t the last in left-first order = the largest object index;
  * the update rule below says exactly that, whatever the order the hits are met in.  A subtree is still skipped only when its
  * entry t lies strictly beyond best t, so no hit of equal t is ever lost. */
-template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false, bool ORDERED = false>
+/* WIDE (with ORDERED): rays without NaN in their slab arithmetic walk the tree two levels at a time through the collapsed
+ * records (sc.bnodes2w: four boxes per visit, the hit ones sorted by entry t, nearest first); the others -- a zero or
+ * non-finite direction component, a non-finite origin -- walk the two-box records as before, lane by lane. */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false, bool ORDERED = false, bool WIDE = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
@@ -1132,6 +1135,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
     const float ninf = -__builtin_huge_valf();
 
     bool alive = false, walking = false;
+    bool wide = false;                  /* WIDE: this lane's ray walks the collapsed records */
     unsigned ri = 0, cur = 0;
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f;
@@ -1152,6 +1156,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                 best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
                 st.sp = 0;
                 cur = sc.root_word;
+                if (WIDE) {
+                    wide = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX && ia != 0.0f && ib != 0.0f && ic != 0.0f &&
+                           fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f;
+                    if (wide) cur = sc.root_word_w;
+                }
                 walking = false;
                 if (sc.n_accel > 0) {                                                  /* root box, intersect.h:381,:454 */
                     float t0;
@@ -1175,6 +1184,30 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                         if (t < CRT_TMAX && (t < best_t || (t == best_t && idx > best_idx))) { best_t = t; best = h; best_idx = idx; }
                     }
                     else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
+                } else if (WIDE && wide) {
+                    const float4* nd = sc.bnodes2w + (size_t)cur * 8;
+                    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
+                    if (COUNT) c_nodes += 4;
+                    const float mnx[4] = { q0.x, q0.y, q0.z, q0.w }, mny[4] = { q1.x, q1.y, q1.z, q1.w }, mnz[4] = { q2.x, q2.y, q2.z, q2.w };
+                    const float mxx[4] = { q3.x, q3.y, q3.z, q3.w }, mxy[4] = { q4.x, q4.y, q4.z, q4.w }, mxz[4] = { q5.x, q5.y, q5.z, q5.w };
+                    unsigned wd[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+                    float key[4];
+                    const float pinf = __builtin_huge_valf();
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float lo[3] = { mnx[c], mny[c], mnz[c] }, hi[3] = { mxx[c], mxy[c], mxz[c] };
+                        float t0;
+                        const float bt = dev_ray_aabb_inv(lo, hi, ray, ia, ib, ic, &t0);
+                        const float kc = t0 > CRT_K_EPSILON ? t0 : ninf;
+                        key[c] = (bt < CRT_TMAX && !(kc > best_t)) ? kc : pinf;           /* +inf: not to be visited */
+                    }
+#define CRT_CSWAP(a, b) { if (key[b] < key[a]) { const float tk = key[a]; key[a] = key[b]; key[b] = tk; const unsigned tw = wd[a]; wd[a] = wd[b]; wd[b] = tw; } }
+                    CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
+#undef CRT_CSWAP
+                    if (key[3] < pinf) st.push(wd[3], key[3]);
+                    if (key[2] < pinf) st.push(wd[2], key[2]);
+                    if (key[1] < pinf) st.push(wd[1], key[1]);
+                    if (key[0] < pinf) { cur = wd[0]; need_pop = false; }
                 } else {
                     const float4* nd = sc.bnodes2 + (size_t)cur * 4;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];

@@ -262,6 +262,7 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
     for accel, knob, settings in ((api.ACCEL_BVH4, "CRT_NODE_ORDER", ("0", "1", "2", "8")),
                                   (api.ACCEL_BVH4, "CRT_TAIL_SPLIT_MAX", ("0", "100000000")),
                                   (api.ACCEL_BVH, "CRT_BVH2_ORDERED", ("0", "1")),
+                                  (api.ACCEL_BVH, "CRT_BVH2_WIDE", ("0", "1")),
                                   (api.ACCEL_GRID, "CRT_GRID_SKIP", ("0", "1"))):
         built = api.BuiltScene(si, accel)
         o = ol.OracleScene(si, accel, sort_mode=0)
@@ -270,6 +271,8 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
         cells = []
         if knob == "CRT_NODE_ORDER":                      # visit counts are compared below: the plain walk (which lane takes which
             monkeypatch.setenv("CRT_TAIL_SPLIT_MAX", "0")  # subtree in the tail-splitting walk depends on timing, its counts vary)
+        if knob == "CRT_BVH2_ORDERED":                    # box counts of the two-box walks are compared below
+            monkeypatch.setenv("CRT_BVH2_WIDE", "0")
         for val in settings:
             monkeypatch.setenv(knob, val)
             sc = api.Scene(built, 0)                      # the knob is read here
@@ -283,9 +286,10 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
             assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ), (accel, knob, val)
         monkeypatch.delenv(knob)
         monkeypatch.delenv("CRT_TAIL_SPLIT_MAX", raising=False)
+        monkeypatch.delenv("CRT_BVH2_WIDE", raising=False)
         if accel == api.ACCEL_GRID:                       # skipped cells are still counted as walked
             assert cells[0] == cells[1]
         if knob == "CRT_NODE_ORDER":                      # the same walk whatever the addresses
             assert len(set(cells)) == 1
-        if accel == api.ACCEL_BVH and scene == "blobs":   # nearer child first tests fewer boxes
+        if knob == "CRT_BVH2_ORDERED" and scene == "blobs":   # nearer child first tests fewer boxes
             assert cells[1] < cells[0]
