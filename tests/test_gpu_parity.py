@@ -153,9 +153,12 @@ def test_tiny_scenes():
 
 @pytest.mark.parametrize("mode", [api.TRAVERSE_PRUNED, api.TRAVERSE_EXACT])
 @pytest.mark.parametrize("scene", ["blobs", "analytic"])
-def test_counters_match_the_oracles_walk(scene, mode):
+def test_counters_match_the_oracles_walk(scene, mode, monkeypatch):
     """Same boxes tested and same primitives tested as the oracle's walk in that mode: the GPU walk
     is the same walk, not merely one with the same answers."""
+    # the plain walk: in the tail-splitting walk (small batches) which lane takes which subtree depends on timing, so its
+    # counts vary from run to run by a fraction of a per cent, in either direction
+    monkeypatch.setenv("CRT_TAIL_SPLIT_MAX", "0")
     si = scenes.courtyard(4, 16, 32, seed=2) if scene == "blobs" else scenes.analytic_scene()
     if scene == "blobs":
         rays, ld = rayset(si, 4096, 9)
