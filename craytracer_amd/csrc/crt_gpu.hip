@@ -928,6 +928,34 @@ int crt_scene_set_traverse_mode(crt_scene* s, int mode)
     s->mode = mode;
     return CRT_OK;
 }
+int crt_host_grid_distance_field(const crt_scene_desc* desc, uint8_t* out)
+{
+    if (!desc || !out || desc->accel != CRT_ACCEL_GRID) return CRT_E_INVALID;
+    int d4 = 0, d2 = 0;
+    try {
+        const int rc = validate_desc(desc, &d4, &d2);
+        if (rc != CRT_OK) return rc;
+        std::vector<unsigned char> cd;
+        grid_distance_field(desc, cd);
+        if (!cd.empty()) memcpy(out, cd.data(), cd.size());
+    } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
+    return CRT_OK;
+}
+int crt_host_qbvh_node_order(const crt_scene_desc* desc, int policy, int32_t* order, int32_t* num_slots)
+{
+    if (!desc || !order || !num_slots || desc->accel != CRT_ACCEL_BVH4) return CRT_E_INVALID;
+    int d4 = 0, d2 = 0;
+    try {
+        const int rc = validate_desc(desc, &d4, &d2);
+        if (rc != CRT_OK) return rc;
+        std::vector<int> ord, newid;
+        node_layout(desc, policy, ord, newid);
+        if (ord.size() > 2 * (size_t)desc->num_nodes4) return CRT_E_TOOBIG;       /* cannot happen: at most one dead record per cluster */
+        for (size_t i = 0; i < ord.size(); i++) order[i] = ord[i];
+        *num_slots = (int32_t)ord.size();
+    } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
+    return CRT_OK;
+}
 int crt_scene_set_node_compression(crt_scene* s, int on)
 {
     if (!s) return CRT_E_INVALID;

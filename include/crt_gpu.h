@@ -227,6 +227,18 @@ int  crt_scene_set_ray_binning(crt_scene* s, int on);
  * nodes in the same order and returns the same hit records bit for bit. */
 int  crt_scene_set_node_compression(crt_scene* s, int on);
 
+/* Two host-side steps of crt_scene_create, exported so that they can be checked without a GPU (tests/test_host_layout.py).
+ * No counterpart in the reference; neither touches a device.
+ *  - crt_host_grid_distance_field: for a CRT_ACCEL_GRID description, out[cell] = chessboard (Chebyshev) distance from the cell
+ *    to the nearest cell that holds an object (0: holds one), capped at 255; cell = iy*nz*nx + iz*nx + ix as in
+ *    gridIntersectTest (intersect.h:94).  The grid walk steps through the next out[cell] - 1 cells without fetching them.
+ *  - crt_host_qbvh_node_order: the order the QBVH nodes take in device memory under `policy` (0 as handed over, 1 sibling
+ *    clusters, 2 line-aligned sibling clusters, >= 4 treelets of that many nodes).  order[slot] = node index or -1 for a
+ *    dead record; `order` must hold 2 * num_nodes4 entries, *num_slots receives how many were written.  Hit records do not
+ *    depend on the order. */
+int  crt_host_grid_distance_field(const crt_scene_desc* desc, uint8_t* out);
+int  crt_host_qbvh_node_order(const crt_scene_desc* desc, int policy, int32_t* order, int32_t* num_slots);
+
 /* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose
  * H2D copy, kernel and D2H copy are pipelined on two streams; returns when hits[] is complete. */
 int  crt_intersect_batch(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits);

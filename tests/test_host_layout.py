@@ -1,0 +1,81 @@
+"""Host-side steps of crt_scene_create that need no GPU: the uniform grid's distance field and the QBVH node order."""
+import ctypes as C
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from craytracer_amd import api, scenes
+
+
+def _distance_field(built):
+    g = built.desc.grid
+    out = np.zeros(g.num_cells, np.uint8)
+    rc = api.lib().crt_host_grid_distance_field(C.byref(built.desc), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out.reshape(g.ny, g.nz, g.nx)          # cell = iy*nz*nx + iz*nx + ix (intersect.h:94)
+
+
+@pytest.mark.parametrize("scene", ["blobs", "soup", "one"])
+def test_grid_distance_field_is_the_chessboard_distance_to_the_nearest_occupied_cell(scene):
+    si = {"blobs": lambda: scenes.courtyard(2, 12, 24, seed=3),
+          "soup": lambda: scenes.random_tris(300, seed=8, size=0.02),
+          "one": lambda: scenes.random_tris(1, seed=2, size=0.3)}[scene]()
+    built = api.BuiltScene(si, api.ACCEL_GRID)
+    g = built.desc.grid
+    cs = built.cell_start
+    occupied = (cs[1:] > cs[:-1]).reshape(g.ny, g.nz, g.nx)
+    assert occupied.any()
+    got = _distance_field(built)
+    want = ndimage.distance_transform_cdt(~occupied, metric="chessboard")     # 0 on occupied cells
+    assert np.array_equal(got, np.minimum(want, 255).astype(np.uint8))
+    assert (got[occupied] == 0).all() and (got[~occupied] > 0).all()
+    # the property the walk relies on: a cell at distance d has no occupied cell within d - 1 steps along any axis path
+    d = int(got.max())
+    if d > 1:
+        iy, iz, ix = np.argwhere(got == d)[0]
+        lo = lambda v: max(v - (d - 1), 0)
+        assert not occupied[lo(iy):iy + d, lo(iz):iz + d, lo(ix):ix + d].any()
+    built.close()
+
+
+def test_distance_field_refuses_other_accelerators():
+    built = api.BuiltScene(scenes.random_tris(50, seed=1), api.ACCEL_BVH4)
+    out = np.zeros(16, np.uint8)
+    assert api.lib().crt_host_grid_distance_field(C.byref(built.desc), out.ctypes.data_as(C.c_void_p)) != 0
+    built.close()
+
+
+@pytest.mark.parametrize("sah", [False, True])
+@pytest.mark.parametrize("policy", [0, 1, 2, 4, 16])
+def test_qbvh_node_order_is_a_permutation_with_the_root_first(policy, sah):
+    si = scenes.courtyard(3, 12, 24, seed=4)
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=sah)
+    n = built.desc.num_nodes4
+    order = np.full(2 * n, -2, np.int32)
+    slots = C.c_int32(0)
+    rc = api.lib().crt_host_qbvh_node_order(C.byref(built.desc), policy, order.ctypes.data_as(C.c_void_p), C.byref(slots))
+    assert rc == 0
+    order = order[:slots.value]
+    live = order[order >= 0]
+    assert order[0] == 0                                         # the walk starts at slot 0
+    assert np.array_equal(np.sort(live), np.arange(n))           # every node exactly once
+    dead = int((order < 0).sum())
+    assert (order[order < 0] == -1).all()
+    if policy != 2:
+        assert dead == 0
+    else:                                                        # a cluster of two or more inner children starts on a 128-byte line
+        assert dead < n
+    nodes = built.nodes4
+    slot_of = np.empty(n, np.int64)
+    slot_of[live] = np.nonzero(order >= 0)[0]
+    if policy in (1, 2):                                         # the inner children of a node lie side by side
+        for i in range(n):
+            kids = [int(nodes["child"][i][c]) for c in range(4) if nodes["type"][i][c] == -1]
+            if len(kids) >= 2:
+                s = sorted(slot_of[kids])
+                assert s[-1] - s[0] == len(kids) - 1
+                if policy == 2:
+                    assert s[0] % 2 == 0
+    if policy == 0:
+        assert np.array_equal(order, np.arange(n))
+    built.close()
