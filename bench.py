@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--no-reference-tree", action="store_true",
                     help="skip the leg that repeats the batch on the reference's median-split tree (profiling runs: it launches "
                          "the same kernel, so per-kernel profile averages would mix the two trees)")
+    ap.add_argument("--no-other-accels", action="store_true", help="skip the binary-BVH / uniform-grid figures of the default line")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
     ap.add_argument("--render-spp", type=int, default=32, help="samples per pixel per GPU timed in the render leg")
     ap.add_argument("--render-cpu-spp", type=int, default=48, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
@@ -591,6 +592,40 @@ def main():
                                        n_copies, n_lat, n_lon)
         except Exception as e:  # the headline line must not depend on this leg
             out["render"] = {"error": repr(e)[:300]}
+
+    if not shadow and args.accel == "bvh4" and world == 1 and not args.no_other_accels:
+        # the reference's other two accelerators on the same kind of rays: extra figures, not the headline.
+        # Each scene makes its own incoherent batch (bounce rays traced through that scene), as `--accel bvh|grid` does.
+        others = {}
+        for name, a_id, wl in (("binary_bvh", api.ACCEL_BVH, args.workload), ("uniform_grid", api.ACCEL_GRID, "courtyard-1M")):
+            try:
+                o_si = si if wl == args.workload else scenes.courtyard(*WORKLOADS[wl], seed=5)
+                o_built = api.BuiltScene(o_si, a_id)
+                o_sc = api.Scene(o_built, local_rank)
+                o_rays = gen_incoherent_rays(o_sc, o_si, n, 0xC0FFEE + rank, device)
+                o_hits = torch.empty((n, 5), dtype=torch.int32, device=device)
+                ms = []
+                for _ in range(4):
+                    o_sc.intersect_dev(o_rays.data_ptr(), n, o_hits.data_ptr(), stream)
+                    ms.append(o_sc.last_kernel_ms() + o_sc.last_binning_ms())
+                c_ms = float(np.mean(ms[1:]))
+                s_rays, s_ld = gen_shadow_rays(o_sc, o_si, o_rays, 0xBEEF + rank, device)
+                s_t = torch.empty(n, dtype=torch.float32, device=device)
+                s_occ = torch.empty(n, dtype=torch.uint8, device=device)
+                ms = []
+                for _ in range(4):
+                    o_sc.shadow_dev(s_rays.data_ptr(), s_ld.data_ptr(), n, s_t.data_ptr(), s_occ.data_ptr(), stream)
+                    ms.append(o_sc.last_kernel_ms() + o_sc.last_binning_ms())
+                a_ms = float(np.mean(ms[1:]))
+                others[name] = {"workload": wl, "triangles": o_si.num_obj, "rays": n,
+                                "closest_hit_mrays": round(n / c_ms / 1e3, 1), "any_hit_mrays": round(n / a_ms / 1e3, 1),
+                                "hits_checksum": int(o_hits.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF}
+                del o_rays, o_hits, s_rays, s_ld, s_t, s_occ
+                o_sc.close()
+                o_built.close()
+            except Exception as e:
+                others[name] = {"error": repr(e)[:300]}
+        out["other_accelerators"] = others
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU checker timed as "the reference's path on the host cores": same tree, same rays

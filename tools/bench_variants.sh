@@ -5,7 +5,7 @@ P=$1; shift
 mkdir -p gpurun_out
 for n in "$@"; do
   if [ "$n" = main ]; then unset CRT_GPU_LIB; else export CRT_GPU_LIB=$GRAFT_REPO_ROOT/variants/libcrt_$n.so; fi
-  timeout -k 10 ${VARIANT_TIMEOUT:-300} python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-render --no-reference-tree ${BENCH_ARGS:-} > gpurun_out/${P}_$n.log 2>&1 || { echo "$n FAILED"; tail -3 gpurun_out/${P}_$n.log; exit 1; }
+  timeout -k 10 ${VARIANT_TIMEOUT:-300} python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-render --no-reference-tree --no-other-accels ${BENCH_ARGS:-} > gpurun_out/${P}_$n.log 2>&1 || { echo "$n FAILED"; tail -3 gpurun_out/${P}_$n.log; exit 1; }
   python3 - "$n" gpurun_out/${P}_$n.log <<'PY'
 import json,sys
 l=[x for x in open(sys.argv[2]) if x.startswith('{')][-1]

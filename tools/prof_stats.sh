@@ -15,7 +15,7 @@ run() {  # name, bench args...
   echo "$name done"
 }
 run full
-run walk_with_reference_tree --no-render
-run walk --no-render --no-reference-tree   # the headline launches alone: this average is the one roofline.kernel_ms must match
+run walk_with_reference_tree --no-render --no-other-accels
+run walk --no-render --no-reference-tree --no-other-accels   # the headline launches alone: this average is the one roofline.kernel_ms must match
 run bvh --no-render --accel bvh
 run grid --no-render --accel grid --workload courtyard-1M

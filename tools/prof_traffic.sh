@@ -25,7 +25,7 @@ for b in $BUILDERS; do
   i=0
   for p in "${PASSES[@]}"; do
    i=$((i+1))
-   timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d $D/pass$i -- python3 $R/bench.py --no-cpu-baseline --no-reference-tree --no-render --steps 5 --warmup 1 --builder $b --mode $m > $D/pass$i.log 2>&1 || { echo "$b $m pass $i failed"; tail -5 $D/pass$i.log; exit 1; }
+   timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d $D/pass$i -- python3 $R/bench.py --no-cpu-baseline --no-reference-tree --no-render --no-other-accels --steps 5 --warmup 1 --builder $b --mode $m > $D/pass$i.log 2>&1 || { echo "$b $m pass $i failed"; tail -5 $D/pass$i.log; exit 1; }
    echo "$b $m pass $i done"
   done
   python3 $R/tools/pmc_summary.py $D > $D/summary.txt
