@@ -52,6 +52,9 @@ for d in sorted(os.listdir(src)):
     if "SQ_BUSY_CYCLES" in vals and vals.get("SQ_ACTIVE_INST_VALU"):
         e["valu_instructions"] = vals.get("SQ_INSTS_VALU")
         e["salu_instructions"] = vals.get("SQ_INSTS_SALU")
+    if vals.get("GRBM_GUI_ACTIVE") and vals.get("SQ_ACTIVE_INST_VALU"):
+        # a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1 024 SIMDs
+        e["valu_issue_utilisation"] = round(4.0 * vals["SQ_ACTIVE_INST_VALU"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4)
     if "SQ_WAVES" in vals:
         e["waves_per_simd"] = round(vals["SQ_WAVES"] / 1024.0, 2)
     db[key] = e
