@@ -254,6 +254,78 @@ void grid_distance_field(const crt_scene_desc* d, std::vector<unsigned char>& ou
         memcpy(&out[((size_t)iy * nz + iz) * nx], &v[at(0, iy, iz)], (size_t)nx);
 }
 
+/* Binary BVH: does a left-first depth-first walk meet the leaves in strictly increasing object index?  (BVH_build's in-place
+ * partition gives that.)  Then "the last of equal hits in left-first order" (intersect.h:339, t1 < t2 ? left : right) is "the
+ * largest object index", whatever order a walk meets them in. */
+bool bvh2_leaves_in_index_order(const crt_scene_desc* desc)
+{
+    if (desc->num_nodes2 < 1) return false;
+    std::vector<int> stack;
+    stack.push_back(0);
+    int last = -1;
+    while (!stack.empty()) {
+        const int node = stack.back(); stack.pop_back();
+        const crt_bvh2_node& c = desc->nodes2[node];
+        if (c.left < 0) { if (!(c.right > last)) return false; last = c.right; }
+        else { stack.push_back(c.right); stack.push_back(c.left); }
+    }
+    return true;
+}
+
+/* Binary BVH, two levels at a time: a 128-byte record per binary inner node of every other level, holding the boxes of its (up
+ * to four) grandchildren -- a child that is a leaf takes one slot itself:
+ *   rows 0..5 = minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4], row 6 = four child words (record index, CRT_LEAF_BIT | object,
+ *   or 0xFFFFFFFF with an inverted box for an unused slot), row 7 unused.  Record 0 is the root's.
+ * The intermediate child's own box is then never tested; that changes nothing for a ray without NaN in its slab arithmetic,
+ * because a box that contains another passes the reference's test whenever the inner one does (subtraction and multiplication
+ * by one factor are monotone), and the containment is checked here.  Half the dependent steps per ray.  False: the tree does
+ * not qualify (a root that is a leaf, a child box sticking out of its parent's, a tree too deep for the walk's stack). */
+bool bvh2_collapse(const crt_scene_desc* desc, int depth, std::vector<float4>& b2w)
+{
+    b2w.clear();
+    if (desc->num_nodes2 < 1 || desc->nodes2[0].left < 0 || 3 * ((depth + 1) / 2) + 1 > CRT_STACK_MAX) return false;
+    std::vector<int> rec_of((size_t)desc->num_nodes2, -1), rec_nodes;
+    rec_of[0] = 0; rec_nodes.push_back(0);
+    auto inside = [&](int c, int p) -> bool {
+        const crt_bvh2_node& a = desc->nodes2[c]; const crt_bvh2_node& b = desc->nodes2[p];
+        for (int k = 0; k < 3; k++) if (!(a.bmin[k] >= b.bmin[k] && a.bmax[k] <= b.bmax[k])) return false;
+        return true;
+    };
+    for (size_t r = 0; r < rec_nodes.size(); r++) {
+        const crt_bvh2_node& nd = desc->nodes2[rec_nodes[r]];
+        int slots[4], ns = 0;
+        const int kids[2] = { nd.left, nd.right };
+        for (int k = 0; k < 2; k++) {
+            const crt_bvh2_node& c = desc->nodes2[kids[k]];
+            if (c.left < 0) slots[ns++] = kids[k];
+            else {
+                if (!inside(c.left, kids[k]) || !inside(c.right, kids[k])) { b2w.clear(); return false; }
+                slots[ns++] = c.left; slots[ns++] = c.right;
+            }
+        }
+        b2w.resize((r + 1) * 8);
+        float bx[6][4]; unsigned wd[4];
+        for (int c = 0; c < 4; c++) {
+            for (int k = 0; k < 3; k++) { bx[k][c] = CRT_TMAX; bx[3 + k][c] = -CRT_TMAX; }     /* empty slot: never hit */
+            wd[c] = 0xFFFFFFFFu;
+            if (c >= ns) continue;
+            const crt_bvh2_node& sn = desc->nodes2[slots[c]];
+            for (int k = 0; k < 3; k++) { bx[k][c] = sn.bmin[k]; bx[3 + k][c] = sn.bmax[k]; }
+            if (sn.left < 0) wd[c] = CRT_LEAF_BIT | (unsigned)sn.right;
+            else {
+                if (rec_of[slots[c]] < 0) { rec_of[slots[c]] = (int)rec_nodes.size(); rec_nodes.push_back(slots[c]); }
+                wd[c] = (unsigned)rec_of[slots[c]];
+            }
+        }
+        float4* q = &b2w[r * 8];
+        for (int k = 0; k < 6; k++) q[k] = make_float4(bx[k][0], bx[k][1], bx[k][2], bx[k][3]);
+        float wf[4]; memcpy(wf, wd, 16);
+        q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
+        q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return true;
+}
+
 int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
 {
     if (!d || d->num_obj < 0 || d->num_non_grid_obj < 0 || d->num_non_grid_obj > d->num_obj) return CRT_E_INVALID;
@@ -755,71 +827,12 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 q[3] = make_float4(lf, rf, 0.0f, 0.0f);
             }
             s->root_word2 = word(0);
-            {   /* leaves in left-first depth-first order: strictly increasing object index? */
-                std::vector<int> stack;
-                stack.push_back(0);
-                int last = -1;
-                bool inc = true;
-                while (!stack.empty() && inc) {
-                    const int node = stack.back(); stack.pop_back();
-                    const crt_bvh2_node& c = desc->nodes2[node];
-                    if (c.left < 0) { inc = c.right > last; last = c.right; }
-                    else { stack.push_back(c.right); stack.push_back(c.left); }
-                }
-                const char* e = getenv("CRT_BVH2_ORDERED");
-                s->bvh2_ordered = inc && !(e && atoi(e) == 0);
-            }
-            /* Two levels at a time: a record per binary inner node at every other level, holding the boxes of its (up to four)
-             * grandchildren -- a child that is a leaf takes one slot itself.  The intermediate child's own box is then never tested;
-             * that changes nothing for a ray without NaN in its slab arithmetic, because a box that contains another passes the
-             * reference's test whenever the inner one does (subtraction and multiplication by one factor are monotone), and the
-             * containment is checked here.  Half the dependent steps per ray. */
             {
-                const char* e = getenv("CRT_BVH2_WIDE");
-                bool ok = s->bvh2_ordered && !(e && atoi(e) == 0) && desc->nodes2[0].left >= 0 && 3 * ((d2 + 1) / 2) + 1 <= CRT_STACK_MAX;
-                std::vector<int> rec_of((size_t)desc->num_nodes2, -1), rec_nodes;
-                if (ok) { rec_of[0] = 0; rec_nodes.push_back(0); }
-                auto inside = [&](int c, int p) -> bool {
-                    const crt_bvh2_node& a = desc->nodes2[c]; const crt_bvh2_node& b = desc->nodes2[p];
-                    for (int k = 0; k < 3; k++) if (!(a.bmin[k] >= b.bmin[k] && a.bmax[k] <= b.bmax[k])) return false;
-                    return true;
-                };
-                for (size_t r = 0; ok && r < rec_nodes.size(); r++) {
-                    const int node = rec_nodes[r];
-                    const crt_bvh2_node& nd = desc->nodes2[node];
-                    int slots[4], ns = 0;
-                    const int kids[2] = { nd.left, nd.right };
-                    for (int k = 0; k < 2 && ok; k++) {
-                        const crt_bvh2_node& c = desc->nodes2[kids[k]];
-                        if (c.left < 0) slots[ns++] = kids[k];
-                        else {
-                            ok = inside(c.left, kids[k]) && inside(c.right, kids[k]);
-                            slots[ns++] = c.left; slots[ns++] = c.right;
-                        }
-                    }
-                    if (!ok) break;
-                    b2w.resize((r + 1) * 8);
-                    float bx[6][4]; unsigned wd[4];
-                    for (int c = 0; c < 4; c++) {
-                        for (int k = 0; k < 3; k++) { bx[k][c] = CRT_TMAX; bx[3 + k][c] = -CRT_TMAX; }     /* empty slot: never hit */
-                        wd[c] = 0xFFFFFFFFu;
-                        if (c >= ns) continue;
-                        const crt_bvh2_node& sn = desc->nodes2[slots[c]];
-                        for (int k = 0; k < 3; k++) { bx[k][c] = sn.bmin[k]; bx[3 + k][c] = sn.bmax[k]; }
-                        if (sn.left < 0) wd[c] = CRT_LEAF_BIT | (unsigned)sn.right;
-                        else {
-                            if (rec_of[slots[c]] < 0) { rec_of[slots[c]] = (int)rec_nodes.size(); rec_nodes.push_back(slots[c]); }
-                            wd[c] = (unsigned)rec_of[slots[c]];
-                        }
-                    }
-                    float4* q = &b2w[r * 8];
-                    for (int k = 0; k < 6; k++) q[k] = make_float4(bx[k][0], bx[k][1], bx[k][2], bx[k][3]);
-                    float wf[4]; memcpy(wf, wd, 16);
-                    q[6] = make_float4(wf[0], wf[1], wf[2], wf[3]);
-                    q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                if (!ok) b2w.clear();
-                s->bvh2_wide = ok;
+                const char* e = getenv("CRT_BVH2_ORDERED");
+                s->bvh2_ordered = bvh2_leaves_in_index_order(desc) && !(e && atoi(e) == 0);
+                e = getenv("CRT_BVH2_WIDE");
+                s->bvh2_wide = s->bvh2_ordered && !(e && atoi(e) == 0) && bvh2_collapse(desc, d2, b2w);
+                if (!s->bvh2_wide) b2w.clear();
                 s->root_word2w = 0u;
             }
             for (int a = 0; a < 3; a++) { s->dev.root_bmin[a] = desc->nodes2[0].bmin[a]; s->dev.root_bmax[a] = desc->nodes2[0].bmax[a]; }
@@ -938,6 +951,21 @@ int crt_host_grid_distance_field(const crt_scene_desc* desc, uint8_t* out)
         std::vector<unsigned char> cd;
         grid_distance_field(desc, cd);
         if (!cd.empty()) memcpy(out, cd.data(), cd.size());
+    } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
+    return CRT_OK;
+}
+int crt_host_bvh2_wide_records(const crt_scene_desc* desc, float* records, int32_t* num_records, int32_t* leaves_in_index_order)
+{
+    if (!desc || !num_records || !leaves_in_index_order || desc->accel != CRT_ACCEL_BVH) return CRT_E_INVALID;
+    int d4 = 0, d2 = 0;
+    try {
+        const int rc = validate_desc(desc, &d4, &d2);
+        if (rc != CRT_OK) return rc;
+        *leaves_in_index_order = bvh2_leaves_in_index_order(desc) ? 1 : 0;
+        std::vector<float4> b2w;
+        const bool ok = *leaves_in_index_order && bvh2_collapse(desc, d2, b2w);
+        *num_records = ok ? (int32_t)(b2w.size() / 8) : 0;
+        if (ok && records) memcpy(records, b2w.data(), b2w.size() * sizeof(float4));
     } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
     return CRT_OK;
 }

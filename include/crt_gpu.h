@@ -227,7 +227,7 @@ int  crt_scene_set_ray_binning(crt_scene* s, int on);
  * nodes in the same order and returns the same hit records bit for bit. */
 int  crt_scene_set_node_compression(crt_scene* s, int on);
 
-/* Two host-side steps of crt_scene_create, exported so that they can be checked without a GPU (tests/test_host_layout.py).
+/* Three host-side steps of crt_scene_create, exported so that they can be checked without a GPU (tests/test_host_layout.py).
  * No counterpart in the reference; neither touches a device.
  *  - crt_host_grid_distance_field: for a CRT_ACCEL_GRID description, out[cell] = chessboard (Chebyshev) distance from the cell
  *    to the nearest cell that holds an object (0: holds one), capped at 255; cell = iy*nz*nx + iz*nx + ix as in
@@ -238,6 +238,13 @@ int  crt_scene_set_node_compression(crt_scene* s, int on);
  *    depend on the order. */
 int  crt_host_grid_distance_field(const crt_scene_desc* desc, uint8_t* out);
 int  crt_host_qbvh_node_order(const crt_scene_desc* desc, int policy, int32_t* order, int32_t* num_slots);
+/*  - crt_host_bvh2_wide_records: for a CRT_ACCEL_BVH description, whether a left-first walk meets the leaves in increasing object
+ *    index (then the pruned walk may take the nearer child first and settle equal t by index: intersect.h:339 keeps the last of
+ *    equal hits in left-first order), and the tree collapsed two levels at a time: 32 floats per record = minx[4] miny[4] minz[4]
+ *    maxx[4] maxy[4] maxz[4], four child words (record index, 0x80000000 | object index, 0xFFFFFFFF = unused slot), four unused.
+ *    `records` may be null (count only) and otherwise holds at most num_nodes2 records; *num_records = 0 when the tree does
+ *    not qualify. */
+int  crt_host_bvh2_wide_records(const crt_scene_desc* desc, float* records, int32_t* num_records, int32_t* leaves_in_index_order);
 
 /* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose
  * H2D copy, kernel and D2H copy are pipelined on two streams; returns when hits[] is complete. */

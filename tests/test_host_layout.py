@@ -79,3 +79,61 @@ def test_qbvh_node_order_is_a_permutation_with_the_root_first(policy, sah):
     if policy == 0:
         assert np.array_equal(order, np.arange(n))
     built.close()
+
+
+@pytest.mark.parametrize("scene", ["blobs", "soup", "pair"])
+def test_binary_bvh_collapsed_two_levels_per_record(scene):
+    """Every record holds its node's grandchildren (a leaf child stands for itself), with their boxes as the tree has them;
+    walking the records reaches every object exactly once, and left-first order meets them by increasing index."""
+    si = {"blobs": lambda: scenes.courtyard(2, 12, 24, seed=7),
+          "soup": lambda: scenes.random_tris(777, seed=5, size=0.05),
+          "pair": lambda: scenes.random_tris(2, seed=1, size=0.2)}[scene]()
+    built = api.BuiltScene(si, api.ACCEL_BVH)
+    nodes = built.nodes2
+    n = C.c_int32(0)
+    ordered = C.c_int32(0)
+    assert api.lib().crt_host_bvh2_wide_records(C.byref(built.desc), None, C.byref(n), C.byref(ordered)) == 0
+    assert ordered.value == 1 and n.value >= 1
+    rec = np.zeros((n.value, 8, 4), np.float32)
+    assert api.lib().crt_host_bvh2_wide_records(C.byref(built.desc), rec.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(ordered)) == 0
+    words = rec[:, 6, :].view(np.uint32)
+    LEAF = 0x80000000
+
+    def expand(node):                       # the slots a record of `node` must hold, in order
+        out = []
+        for kid in (int(nodes["left"][node]), int(nodes["right"][node])):
+            if nodes["left"][kid] < 0:
+                out.append(kid)
+            else:
+                out += [int(nodes["left"][kid]), int(nodes["right"][kid])]
+        return out
+
+    seen_objects = []
+    rec_node = {0: 0}                       # record index -> binary node it was made from
+    for r in range(n.value):
+        slots = expand(rec_node[r])
+        for c in range(4):
+            w = int(words[r, c])
+            if c >= len(slots):
+                assert w == 0xFFFFFFFF
+                assert (rec[r, 0:3, c] > rec[r, 3:6, c]).all()           # inverted box: never hit
+                continue
+            s = slots[c]
+            assert np.array_equal(rec[r, 0:3, c], nodes["bmin"][s]) and np.array_equal(rec[r, 3:6, c], nodes["bmax"][s])
+            if nodes["left"][s] < 0:
+                assert w == (LEAF | int(nodes["right"][s]))
+                seen_objects.append(int(nodes["right"][s]))
+            else:
+                assert w < n.value and w not in rec_node                    # a tree: every record has one parent
+                rec_node[w] = s
+    assert len(rec_node) == n.value
+    assert sorted(seen_objects) == list(range(si.num_obj))
+    built.close()
+
+
+def test_binary_bvh_of_one_object_is_not_collapsed():
+    built = api.BuiltScene(scenes.random_tris(1, seed=3, size=0.2), api.ACCEL_BVH)
+    n, ordered = C.c_int32(-1), C.c_int32(-1)
+    assert api.lib().crt_host_bvh2_wide_records(C.byref(built.desc), None, C.byref(n), C.byref(ordered)) == 0
+    assert n.value == 0 and ordered.value == 1                            # the root is a leaf: the two-box walk handles it
+    built.close()
