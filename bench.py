@@ -307,6 +307,10 @@ def main():
     if args.builder == "sah" and args.accel != "bvh4":
         raise SystemExit("--builder sah is a QBVH option")
 
+    if os.environ.get("BENCH_DUMP_AFTER"):              # debugging aid: every rank dumps its Python stack after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_AFTER"]), exit=False)
+
     import torch
     from craytracer_amd import api, scenes, shard
 
@@ -326,6 +330,13 @@ def main():
     device = torch.device("cuda", local_rank)
     red_device = device if args.dist_backend == "nccl" else "cpu"     # where the timing scalars are reduced
 
+    t_start = time.time()
+
+    def progress(what):
+        """one line on stderr per leg (rank 0): a harness that takes silence for a hang sees the run moving; stdout stays one JSON line"""
+        if rank == 0:
+            print("[bench %6.1f s] %s" % (time.time() - t_start, what), file=sys.stderr, flush=True)
+
     # ---- scene (full replica per GPU) ----
     t0 = time.time()
     n_copies, n_lat, n_lon = WORKLOADS[args.workload]
@@ -344,6 +355,7 @@ def main():
     n = args.rays
     stream = torch.cuda.current_stream().cuda_stream
     shadow = args.mode == "shadow"
+    progress("scene built and uploaded (%d triangles)" % n_tris)
     d_rays = gen_incoherent_rays(sc, si, n, 0xC0FFEE + rank, device)
     d_ld = None
     if shadow:
@@ -422,6 +434,7 @@ def main():
     bytes_per_ray = algorithmic_bytes(nodes_per_ray, tris_per_ray)
 
     strong_is_value = args.scaling == "strong" and world > 1
+    progress("rays generated, counters taken; timing the headline leg")
     elapsed, kernel_ms, bin_ms = timed(step_strong if strong_is_value else step_weak, args.steps, args.warmup, True)
     rays_per_step = float(n) if strong_is_value else float(n) * world
     value = rays_per_step * args.steps / elapsed / 1e6
@@ -524,6 +537,7 @@ def main():
     if other:
         out[other["scaling"] + "_scaling"] = other
 
+    progress("headline leg done")
     if not shadow and args.accel == "bvh4":
         # secondary metric (BASELINE.json: "any-hit Mrays/s"), outside the timed region: shadow rays from
         # this batch's hit points toward a ceiling light, same scene, three launches
@@ -541,6 +555,7 @@ def main():
                           "occluded_fraction": round(float(s_occ.float().mean().item()), 4)}
         del s_rays, s_ld, s_t, s_occ
 
+    progress("any-hit leg done")
     if not shadow and args.accel == "bvh4" and args.builder == "sah" and not args.no_reference_tree:
         # the same rays through the tree the reference's own builder makes (integration route (b): the host keeps BVH4_build):
         # rate, its own roofline block, and how many hit records differ between the two trees
@@ -581,6 +596,7 @@ def main():
         except Exception as e:
             out["reference_tree"] = {"error": repr(e)[:300]}
 
+    progress("reference-tree leg done")
     if not shadow and args.accel == "bvh4" and not args.no_render:
         # second half of BASELINE.json's metric: samples/sec/pixel of the wavefront path tracer on
         # the same courtyard opened to a constant sky, 4K, depth 5.  Sample passes are sharded over the ranks
@@ -593,6 +609,7 @@ def main():
         except Exception as e:  # the headline line must not depend on this leg
             out["render"] = {"error": repr(e)[:300]}
 
+    progress("render leg done")
     if not shadow and args.accel == "bvh4" and world == 1 and not args.no_other_accels:
         # the reference's other two accelerators on the same kind of rays: extra figures, not the headline.
         # Each scene makes its own incoherent batch (bounce rays traced through that scene), as `--accel bvh|grid` does.
@@ -627,6 +644,7 @@ def main():
                 others[name] = {"error": repr(e)[:300]}
         out["other_accelerators"] = others
 
+    progress("other accelerators done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU checker timed as "the reference's path on the host cores": same tree, same rays
         sys.path.insert(0, os.path.join(ROOT, "tests"))
