@@ -101,10 +101,10 @@ struct crt_scene {
 };
 
 #ifndef CRT_SPLIT_MAX_RAYS_DEFAULT
-#define CRT_SPLIT_MAX_RAYS_DEFAULT 0u             /* opt-in (CRT_TAIL_SPLIT_MAX=<rays>): +18 % at 2^20 rays, +12 % at 2^21, +7 % at 2^22, +3 % at 2^23,
-                                                     -1 % at 2^24.  Off by default out of caution: FOUR bench processes sharing one GPU stalled
-                                                     in the ray-generation phase with it on (3 of 3 tries) -- and once of two tries with it off,
-                                                     so the cause is probably elsewhere (two and three processes never stalled), but it is not found */
+#define CRT_SPLIT_MAX_RAYS_DEFAULT (1u << 23)     /* +18 % at 2^20 rays, +12 % at 2^21, +7 % at 2^22, +3 % at 2^23, -1 % at 2^24 (CRT_TAIL_SPLIT_MAX overrides).
+                                                     A stall of four bench processes sharing one GPU, first seen with this on, reproduces
+                                                     without this library at all (tools/exp/four_procs.py, mode sel+copy: torch selects,
+                                                     randperm and copies only) */
 #endif
 #ifndef CRT_NODE_ORDER_DEFAULT
 #define CRT_NODE_ORDER_DEFAULT 1
