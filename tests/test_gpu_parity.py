@@ -7,6 +7,8 @@ Analytic shapes go through device atan2f/acosf/cbrt/cos, which differ from glibc
 (near-tie class T4): ids may differ only on rays whose oracle hit sits on a window seam,
 and such rays are counted and bounded, not ignored.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -296,3 +298,37 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
             assert len(set(cells)) == 1
         if knob == "CRT_BVH2_ORDERED" and scene == "blobs":   # nearer child first tests fewer boxes
             assert cells[1] < cells[0]
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_binned_batch_of_awkward_rays(accel):
+    """A batch large enough to be binned (>= 2^18 rays, so the ray order, the lane-refill grid walk, the collapsed binary-BVH
+    records and -- for the QBVH -- the tail-splitting walk are all in play) made of the rays that go wrong first: origins
+    outside the scene box, rays that miss it entirely, axis-parallel and -0.0 directions (classes T2 / T3), origins exactly on
+    box planes, next to ordinary incoherent rays.  Every record against the oracle, bit for bit."""
+    si = scenes.courtyard(3, 12, 24, seed=11)
+    lo, hi = scenes.scene_bounds(si)
+    ext = hi - lo
+    n = (1 << 18) + 777                                            # ragged on purpose
+    rng = np.random.Generator(np.random.PCG64(99))
+    rays = scenes.random_rays(n, lo, hi, 5)
+    k = n // 8
+    rays[0:k, 0:3] = (lo - ext) + rng.random((k, 3), dtype=np.float32) * (3 * ext)        # anywhere in a box three times as large
+    rays[k:2 * k] = scenes.axis_parallel_rays(k, lo, hi)                                  # zero / -0.0 components
+    rays[2 * k:3 * k, 0:3] = hi + np.float32(0.5) * ext                                   # outside, pointing away: misses
+    rays[2 * k:3 * k, 3:6] = np.abs(rays[2 * k:3 * k, 3:6])
+    cell = ext / np.float32(16)                                                           # origins exactly on planes of a regular lattice
+    rays[3 * k:4 * k, 0:3] = lo + np.floor(rng.random((k, 3), dtype=np.float32) * 16).astype(np.float32) * cell
+    ld = (rng.random(n, dtype=np.float32) * np.float32(2.0) * np.float32(np.linalg.norm(ext))).astype(np.float32)
+    built = api.BuiltScene(si, accel)
+    sc = api.Scene(built, 0)
+    g_hits = sc.intersect(rays)
+    g_t, g_occ = sc.shadow(rays, ld)
+    sc.close()
+    o = ol.OracleScene(si, accel, sort_mode=0)
+    threads = min(os.cpu_count() or 1, 16)
+    o_hits = o.intersect(rays, mode=api.TRAVERSE_EXACT, nthreads=threads)
+    o_t, o_occ = o.shadow(rays, ld, nthreads=threads)
+    assert ol.same_bits(g_hits, o_hits)
+    assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
+    assert 0.05 < (g_hits["obj"] >= 0).mean() < 0.95               # both outcomes well represented
