@@ -301,13 +301,21 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
 
 
 @pytest.mark.parametrize("accel", ACCELS)
-def test_binned_batch_of_awkward_rays(accel):
+@pytest.mark.parametrize("scene", ["blobs", "cornell29", "analytic"])
+def test_binned_batch_of_awkward_rays(scene, accel):
     """A batch large enough to be binned (>= 2^18 rays, so the ray order, the lane-refill grid walk, the collapsed binary-BVH
     records and -- for the QBVH -- the tail-splitting walk are all in play) made of the rays that go wrong first: origins
     outside the scene box, rays that miss it entirely, axis-parallel and -0.0 directions (classes T2 / T3), origins exactly on
     box planes, next to ordinary incoherent rays.  Every record against the oracle, bit for bit."""
-    si = scenes.courtyard(3, 12, 24, seed=11)
-    lo, hi = scenes.scene_bounds(si)
+    if scene == "blobs":
+        si = scenes.courtyard(3, 12, 24, seed=11)
+        lo, hi = scenes.scene_bounds(si)
+    elif scene == "cornell29":                                     # rectangles, spheres and triangles: the all-shapes instances, pruned walks
+        si = scenes.cornell29()
+        lo, hi = np.array([-10.0, -10.0, -570.0], np.float32), np.array([570.0, 560.0, 10.0], np.float32)
+    else:                                                          # generic / instanced / compound shapes: the reference-control-flow walks
+        si = scenes.analytic_scene()
+        lo, hi = np.array([-7, -2, -7], np.float32), np.array([7, 5, 7], np.float32)
     ext = hi - lo
     n = (1 << 18) + 777                                            # ragged on purpose
     rng = np.random.Generator(np.random.PCG64(99))
@@ -329,6 +337,11 @@ def test_binned_batch_of_awkward_rays(accel):
     threads = min(os.cpu_count() or 1, 16)
     o_hits = o.intersect(rays, mode=api.TRAVERSE_EXACT, nthreads=threads)
     o_t, o_occ = o.shadow(rays, ld, nthreads=threads)
-    assert ol.same_bits(g_hits, o_hits)
-    assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
-    assert 0.05 < (g_hits["obj"] >= 0).mean() < 0.95               # both outcomes well represented
+    if scene == "blobs":
+        assert ol.same_bits(g_hits, o_hits)
+        assert ol.same_bits(g_t, o_t) and np.array_equal(g_occ, o_occ)
+    else:                                                          # spheres, cylinders, tori: the device-libm seam (class T4) may move a few rays
+        bad = (g_hits["obj"] != o_hits["obj"]) | (g_hits["part"] != o_hits["part"]) | ~close(g_hits["t"], o_hits["t"])
+        assert bad.mean() <= 2e-4, int(bad.sum())
+        assert (~close(g_t, o_t)).mean() <= 2e-4 and (g_occ != o_occ).mean() <= 2e-4
+    assert 0.05 < (g_hits["obj"] >= 0).mean() < 0.98               # both outcomes well represented
