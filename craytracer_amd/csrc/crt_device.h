@@ -40,6 +40,7 @@ struct DevScene {
     const float4* nodes2;
     const int* cell_start;
     const int* cell_items;
+    const float4* cell_objs;           /* grid: the object records again, in cell order (record k belongs to cell_items[k]), or null */
     const unsigned char* cell_dist;    /* per cell: chessboard distance to the nearest occupied cell (0: occupied), crt_gpu.hip grid_distance_field */
     unsigned long long* counters;   /* [4]: rays_closest, rays_shadow, nodes, prims */
     crt_grid grid;
@@ -465,9 +466,8 @@ __device__ __noinline__ float dev_shape(const crt_shape* shapes, int si, const D
 /* rayIntersectObject on final-order object `oi` (shapes/shapes.cpp:4-48).
  * TRI_ONLY kernels never take the shape branch. */
 template <bool TRI_ONLY>
-CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shadow, DHit* h)
+CRT_DEV float dev_object_rec(const DevScene& sc, const float4* rec, const DRay& ray, bool shadow, DHit* h)
 {
-    const float4* rec = sc.objs + (size_t)oi * CRT_OBJ_STRIDE;
     float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     h->obj = __float_as_int(r2.y);
     h->part = 0;
@@ -477,4 +477,9 @@ CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shado
     /* rectangles in line: cornell_box.txt (config C1) is rectangles and triangles, and the general path is two out-of-line calls */
     if (__float_as_int(r2.z) == CRT_RECTANGLE) return dev_rect(sc.shapes[__float_as_int(r2.w)].p, ray, shadow);
     return dev_shape(sc.shapes, __float_as_int(r2.w), ray, shadow, &h->part);
+}
+template <bool TRI_ONLY>
+CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shadow, DHit* h)
+{
+    return dev_object_rec<TRI_ONLY>(sc, sc.objs + (size_t)oi * CRT_OBJ_STRIDE, ray, shadow, h);
 }

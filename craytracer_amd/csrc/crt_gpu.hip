@@ -77,7 +77,7 @@ struct crt_scene {
                                  walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist;
+    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
     unsigned long long* d_counters;
     Scratch own;              /* allocated by crt_scene_create (perm may grow) */
     Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
@@ -415,7 +415,7 @@ int upload(void** dst, const std::vector<T>& v)
 void free_scene(crt_scene* s)
 {
     if (!s) return;
-    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist,
+    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist, s->d_cell_objs,
                      s->d_bnodes2, s->d_bnodes2w, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
                      s->own.bin_hist, s->own.bin_cursor, s->own.perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -844,17 +844,28 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         if (desc->num_shapes > 0) shapes.assign(desc->shapes, desc->shapes + desc->num_shapes);
         std::vector<int32_t> cs, ci;
         std::vector<unsigned char> cd;
+        std::vector<float4> co;
         if (desc->accel == CRT_ACCEL_GRID) {
             cs.assign(desc->cell_start, desc->cell_start + desc->grid.num_cells + 1);
             if (cs.back() > 0) ci.assign(desc->cell_items, desc->cell_items + cs.back());
             grid_distance_field(desc, cd);
+            /* the object records once more, in cell order: a cell's objects lie side by side and the walk needs no item index
+             * (48 bytes per cell reference; left out above 16 GB, the walk then goes through cell_items) */
+            {
+                const char* e2 = getenv("CRT_GRID_CELL_RECORDS");
+                if (!(e2 && atoi(e2) == 0) && (double)ci.size() * CRT_OBJ_STRIDE * sizeof(float4) <= 16.0e9) {
+                    co.resize(ci.size() * CRT_OBJ_STRIDE);
+                    for (size_t k = 0; k < ci.size(); k++)
+                        for (int q = 0; q < CRT_OBJ_STRIDE; q++) co[k * CRT_OBJ_STRIDE + q] = objs[(size_t)ci[k] * CRT_OBJ_STRIDE + q];
+                }
+            }
             const char* e = getenv("CRT_GRID_SKIP");                      /* A/B knob: 0 = no cell is skipped, as the reference walks */
             if (e && atoi(e) == 0) for (size_t c = 0; c < cd.size(); c++) if (cd[c] > 1) cd[c] = 1;
         }
         if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK ||
             (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_bnodes2w, b2w)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK ||
-            (rc = upload(&s->d_cell_dist, cd)) != CRT_OK) {
+            (rc = upload(&s->d_cell_dist, cd)) != CRT_OK || (!co.empty() && (rc = upload(&s->d_cell_objs, co)) != CRT_OK)) {
             free_scene(s);
             return rc;
         }
@@ -901,6 +912,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.nodes2 = (const float4*)s->d_nodes2;
     dv.cell_start = (const int*)s->d_cell_start;
     dv.cell_dist = (const unsigned char*)s->d_cell_dist;
+    dv.cell_objs = (const float4*)s->d_cell_objs;
     dv.cell_items = (const int*)s->d_cell_items;
     dv.counters = s->d_counters;
     dv.grid = desc->grid;

@@ -1352,7 +1352,8 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
                         DHit obj_h = best;
                         for (int k = cb; k < ce; k++) {
                             DHit h;
-                            const float tt = dev_object<TRI_ONLY>(sc, sc.cell_items[k], ray, false, &h);
+                            const float tt = sc.cell_objs ? dev_object_rec<TRI_ONLY>(sc, sc.cell_objs + (size_t)k * CRT_OBJ_STRIDE, ray, false, &h)
+                                                          : dev_object<TRI_ONLY>(sc, sc.cell_items[k], ray, false, &h);
                             if (COUNT) c_prims++;
                             if (tt < obj_t) { obj_t = tt; obj_h = h; }
                         }
@@ -1362,6 +1363,9 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
                     } else {
                         for (int k = cb; k < ce; k++) {
                             DHit h;
+                            /* through the item index: an any-hit ray tests five times the objects of a closest-hit ray, many of them
+                             * again in the next cell -- one record per object stays in the caches, a copy per cell does not
+                             * (654 against 688 Mrays/s) */
                             const float tt = dev_object<TRI_ONLY>(sc, sc.cell_items[k], ray, true, &h);
                             if (COUNT) c_prims++;
                             if (tt < bound) { t = tt; done = true; break; }
@@ -1440,10 +1444,16 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid_refill(DevScene sc, LaunchAr
             if (!finish) {
                 if (k < ce) {
                     DHit h;
-                    const int cur_item = item;
-                    k++;
-                    if (k < ce) item = sc.cell_items[k];
-                    const float tt = dev_object<TRI_ONLY>(sc, cur_item, ray, SHADOW, &h);
+                    float tt;
+                    if (sc.cell_objs) {                                                /* the cell's records lie side by side: no index to fetch */
+                        tt = dev_object_rec<TRI_ONLY>(sc, sc.cell_objs + (size_t)k * CRT_OBJ_STRIDE, ray, SHADOW, &h);
+                        k++;
+                    } else {
+                        const int cur_item = item;
+                        k++;
+                        if (k < ce) item = sc.cell_items[k];
+                        tt = dev_object<TRI_ONLY>(sc, cur_item, ray, SHADOW, &h);
+                    }
                     if (COUNT) c_prims++;
                     if (!SHADOW) {
                         if (tt < obj_t) { obj_t = tt; obj_h = h; }
@@ -1463,7 +1473,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid_refill(DevScene sc, LaunchAr
                         skip_left = sc.cell_dist[cell];
                         if (skip_left == 0u) {
                             k = sc.cell_start[cell]; ce = sc.cell_start[cell + 1];
-                            item = sc.cell_items[k];
+                            if (!sc.cell_objs) item = sc.cell_items[k];
                             if (COUNT) c_nodes++;
                         }
                     }
