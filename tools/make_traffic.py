@@ -17,7 +17,8 @@ path = os.path.join(ROOT, "profiles", "traffic.json")
 db = json.load(open(path)) if os.path.exists(path) else {}
 for d in sorted(os.listdir(src)):
     full = os.path.join(src, d)
-    if not os.path.isdir(full) or not os.path.exists(os.path.join(full, "summary.txt")):
+    if not os.path.isdir(full) or "_" not in d or not os.path.exists(os.path.join(full, "summary.txt")) \
+            or not os.path.exists(os.path.join(full, "bench_line.json")):
         continue
     builder, mode = d.rsplit("_", 1)
     line = json.loads(open(os.path.join(full, "bench_line.json")).read())
