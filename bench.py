@@ -34,6 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PG_TIMEOUT_S = 300             # process-group timeout: a collective that cannot complete fails well inside the driver's 600 s limit
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 
@@ -199,26 +200,59 @@ def src_hash():
     return h.hexdigest()[:12]
 
 
-def spawn_ranks(n_gpus, argv):
+def spawn_ranks(n_gpus, argv, poll_s=0.2, grace_s=5.0):
     """--gpus N without a launcher: start N rank processes of this script (fresh interpreters: this process has
-    not imported torch or touched HIP and never will), relay rank 0's output, fail if any rank fails."""
+    not imported torch or touched HIP and never will), relay rank 0's output, and SUPERVISE them: the children are
+    polled, and when one exits non-zero the others -- which would otherwise sit in a rendezvous or a collective
+    until the process-group timeout -- are terminated (SIGTERM, then SIGKILL after `grace_s`) and the launcher
+    exits non-zero with every return code.  BENCH_LAUNCH_TIMEOUT (seconds, default 540: below the driver's 600)
+    bounds the whole run the same way.  Nothing is ever re-executed in a process that has touched the GPU."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    cores = os.cpu_count() or 1
+    if os.environ.get("OMP_NUM_THREADS"):
+        cores = min(cores, int(os.environ["OMP_NUM_THREADS"]))
+    per_rank = max(1, cores // n_gpus)
+    out0 = tempfile.TemporaryFile()                     # a file, not a pipe: nobody has to drain it while we poll
     procs = []
     for r in range(n_gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("CRT_BUILD_THREADS", str(per_rank))        # host builder threads: this rank's share of the cores
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "540"))
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs):
+            why = "rank %d exited with code %d" % next((i, rc) for i, rc in enumerate(rcs) if rc not in (None, 0))
+        elif time.time() > deadline:
+            why = "BENCH_LAUNCH_TIMEOUT reached"
+        if why:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + grace_s
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(poll_s)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+    if why or any(rcs):
+        raise SystemExit("bench.py: %s; rank exit codes %s (the other ranks were stopped)" % (why or "a rank failed", rcs))
 
 
 def dry_run(args, rank, world):
@@ -229,7 +263,8 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from craytracer_amd import shard
     if world > 1:
-        dist.init_process_group(args.dry_backend)
+        import datetime
+        dist.init_process_group(args.dry_backend, timeout=datetime.timedelta(seconds=PG_TIMEOUT_S))
     n = args.rays
     b, e = shard.shard_range(n, rank, world)
     slices = [None] * world
@@ -241,6 +276,8 @@ def dry_run(args, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
+    if os.environ.get("BENCH_DRY_DIE_RANK") == str(rank):      # test seam: this rank dies mid-run, the others wait in the barrier
+        os._exit(int(os.environ.get("BENCH_DRY_DIE_CODE", "3")))
     if world > 1:
         dist.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0)
@@ -278,6 +315,7 @@ def main():
                          "the same kernel, so per-kernel profile averages would mix the two trees)")
     ap.add_argument("--no-other-accels", action="store_true", help="skip the binary-BVH / uniform-grid figures of the default line")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
+    ap.add_argument("--no-strong-projection", action="store_true", help="N = 1: skip the leg that traces the 8 shares of the batch one by one")
     ap.add_argument("--render-spp", type=int, default=32, help="samples per pixel per GPU timed in the render leg")
     ap.add_argument("--render-cpu-spp", type=int, default=48, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
     ap.add_argument("--mode", default="closest", choices=["closest", "shadow"],
@@ -320,12 +358,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the traversal path")
     if args.dist_backend == "gloo":
+        if world > 2 * torch.cuda.device_count():
+            raise SystemExit("bench.py: --dist-backend gloo maps ranks onto devices round-robin and more than two rank processes "
+                             "per GPU are known to stall in torch's own scan / sort kernels (DESIGN.md (d), \"A scare\"): "
+                             "%d ranks on %d device(s) refused" % (world, torch.cuda.device_count()))
         local_rank = local_rank % torch.cuda.device_count()
     if world > 1:
+        import datetime
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=PG_TIMEOUT_S))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=PG_TIMEOUT_S))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     red_device = device if args.dist_backend == "nccl" else "cpu"     # where the timing scalars are reduced
@@ -385,8 +428,44 @@ def main():
     def step_weak():
         trace(d_rays, d_ld, 0, n)
 
+    def trace_slice(rays, ld, k, count, st=None, which=0):
+        """slice k of `count` of the whole resident batch: the library bins the batch and walks a run of whole cells
+        (crt_*_batch_dev_slice); results land at the rays' own indices"""
+        st = stream if st is None else st
+        if shadow:
+            sc.shadow_dev_slice(rays.data_ptr(), ld.data_ptr(), n, d_t.data_ptr(), d_occ.data_ptr(), k, count, st)
+        else:
+            sc.intersect_dev_slice(rays.data_ptr(), n, (d_hits_b if which else d_hits).data_ptr(), k, count, st)
+
     def step_strong():
-        trace(d_shared, d_shared_ld, lo_s, hi_s - lo_s)
+        trace_slice(d_shared, d_shared_ld, rank, world)
+
+    # Two streams: consecutive steps are independent launches; enqueued alternately on two streams they overlap where the
+    # library allows it (a scene holds two sets of launch scratch) -- the drain tail of one step, its longest rays walking on
+    # alone, runs beside the start of the next.  Every step is complete when the timed region ends.  Closest-hit steps write
+    # alternate result buffers; any-hit steps the same one (identical values).
+    side = [torch.cuda.Stream(device=device) for _ in range(2)]
+    d_hits_b = torch.empty((n, 5), dtype=torch.int32, device=device) if not shadow else None
+
+    def timed2(step_fn, steps, warmup):
+        """as timed(), steps enqueued alternately on two streams: step_fn(stream pointer, 0 | 1)"""
+        for i in range(warmup):
+            step_fn(side[i & 1].cuda_stream, i & 1)
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(steps):
+            step_fn(side[i & 1].cuda_stream, i & 1)
+        barrier()
+        return shard.max_over_ranks(time.perf_counter() - t_start, red_device)
+
+    def step_weak2(st, which):
+        if shadow:
+            sc.shadow_dev(d_rays.data_ptr(), d_ld.data_ptr(), n, d_t.data_ptr(), d_occ.data_ptr(), st)
+        else:
+            sc.intersect_dev(d_rays.data_ptr(), n, (d_hits_b if which else d_hits).data_ptr(), st)
+
+    def step_strong2(st, which):
+        trace_slice(d_shared, d_shared_ld, rank, world, st, which)
 
     def barrier():
         torch.cuda.synchronize()
@@ -440,16 +519,24 @@ def main():
     value = rays_per_step * args.steps / elapsed / 1e6
     other = None
     if world > 1:                                      # the other way of sharing the work: fewer launches, own key
-        o_steps = max(2, min(args.steps, 5))
+        o_steps = max(2, min(args.steps, 6))
         o_el, _, _ = timed(step_weak if strong_is_value else step_strong, o_steps, 1, False)
         o_rays = float(n) * world if strong_is_value else float(n)
         other = {"scaling": "weak" if strong_is_value else "strong", "value": round(o_rays * o_steps / o_el / 1e6, 3), "unit": "Mrays/s",
                  "steps": o_steps, "ms_per_step": round(o_el / o_steps * 1e3, 4),
-                 "rays_per_step_all_gpus": int(o_rays)}
-        step_weak()                                    # leave d_hits holding this rank's own batch for the checks below
-        torch.cuda.synchronize()
-    elif strong_is_value:
-        pass
+                 "rays_per_step_all_gpus": int(o_rays),
+                 "sharding": "one batch, rank k walks share k of %d: whole binning cells in Morton order (crt_intersect_batch_dev_slice)" % world
+                 if not strong_is_value else "every rank its own batch"}
+    # the same steps enqueued alternately on two streams (both ways of sharing the work)
+    two = {}
+    p_steps = max(4, min(args.steps, 10))
+    p_el = timed2(step_weak2, p_steps, 2)
+    two["weak"] = {"value": round(float(n) * world * p_steps / p_el / 1e6, 3), "unit": "Mrays/s", "steps": p_steps, "ms_per_step": round(p_el / p_steps * 1e3, 4)}
+    if world > 1:
+        p_el = timed2(step_strong2, p_steps, 2)
+        two["strong"] = {"value": round(float(n) * p_steps / p_el / 1e6, 3), "unit": "Mrays/s", "steps": p_steps, "ms_per_step": round(p_el / p_steps * 1e3, 4)}
+    step_weak()                                        # leave d_hits holding this rank's own batch for the checks below
+    torch.cuda.synchronize()
     if shadow:
         hit_frac = float(d_occ.float().mean().item())
         checksum = int(d_t.view(torch.int32).to(torch.int64).sum().item() + d_occ.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFF
@@ -536,8 +623,41 @@ def main():
     }
     if other:
         out[other["scaling"] + "_scaling"] = other
+    out["two_streams"] = dict(two, what="the same steps enqueued alternately on two HIP streams: consecutive launches overlap (the drain "
+                                       "tail of one beside the start of the next); not the headline, whose steps run on one stream")
 
     progress("headline leg done")
+    if world == 1 and args.accel == "bvh4" and not shadow and not args.no_strong_projection:
+        # What one GPU can say about strong scaling (ONE batch cut into K shares, Mrays/s(K) = n / max_k time_k): each of the
+        # K = 8 shares of THIS batch traced on its own, as rank k of 8 would (crt_intersect_batch_dev_slice: the whole batch binned, a run
+        # of whole cells walked), wall-clock with the same barriers as the headline.  The shares must tile the batch: every record of
+        # the eight launches together is compared with the full launch's.
+        K = 8
+        full = d_hits.clone()
+        d_hits.fill_(0x7F7F7F7F)
+        wall_ms, wall2_ms, kern_ms, bin_ms_k, rays_k, done = [], [], [], [], [], 0
+        for k in range(K):
+            el, kms, bms = timed(lambda: trace_slice(d_rays, d_ld, k, K), 5, 1, True)
+            wall_ms.append(el / 5 * 1e3)
+            wall2_ms.append(timed2(lambda st, which: trace_slice(d_rays, d_ld, k, K, st, 0), 8, 2) / 8 * 1e3)
+            kern_ms.append(float(np.mean(kms)))
+            bin_ms_k.append(float(np.mean(bms)))
+            now = int((d_hits[:, 1] != 0x7F7F7F7F).sum().item())
+            rays_k.append(now - done)
+            done = now
+        tiles = bool((d_hits == full).all().item())
+        single = elapsed / args.steps * 1e3
+        out["strong_scaling_projection"] = {
+            "what": "one GPU, the K shares of the headline batch traced one after the other; speedup = full-batch ms / slowest share's ms",
+            "slices": K, "sharding": "whole binning cells in Morton order (crt_intersect_batch_dev_slice)",
+            "full_batch_ms": round(single, 4), "share_wall_ms": [round(x, 4) for x in wall_ms], "share_walk_kernel_ms": [round(x, 4) for x in kern_ms],
+            "share_binning_ms": [round(x, 4) for x in bin_ms_k], "share_rays": rays_k,
+            "projected_speedup_at_%d_gpus" % K: round(single / max(wall_ms), 3),
+            "two_streams": {"full_batch_ms": two["weak"]["ms_per_step"], "share_wall_ms": [round(x, 4) for x in wall2_ms],
+                            "projected_speedup_at_%d_gpus" % K: round(two["weak"]["ms_per_step"] / max(wall2_ms), 3)},
+            "shares_tile_the_batch_bit_identically": tiles}
+        del full
+        progress("strong-scaling projection done")
     if not shadow and args.accel == "bvh4":
         # secondary metric (BASELINE.json: "any-hit Mrays/s"), outside the timed region: shadow rays from
         # this batch's hit points toward a ceiling light, same scene, three launches
@@ -603,7 +723,7 @@ def main():
         # (each renders its own sample range of the full frame); the colour buffers are summed over RCCL
         # inside the timed region.
         try:
-            del d_rays, d_hits, d_shared
+            del d_rays, d_hits, d_shared, d_hits_b
             out["render"] = render_leg(args, api, scenes, shard, torch, rank, world, local_rank, device, red_device, barrier,
                                        n_copies, n_lat, n_lon)
         except Exception as e:  # the headline line must not depend on this leg

@@ -161,7 +161,7 @@ EXPORTS = [
     "crt_host_grid_distance_field", "crt_host_qbvh_node_order", "crt_host_bvh2_wide_records",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
-    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_intersect_batch_dev_counted", "crt_shadow_batch_dev_counted", "crt_fill_shade_rec",
+    "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_intersect_batch_dev_slice", "crt_shadow_batch_dev_slice", "crt_scene_reserve_rays", "crt_intersect_batch_dev_counted", "crt_shadow_batch_dev_counted", "crt_fill_shade_rec",
     "crt_scene_enable_counters", "crt_scene_get_counters", "crt_scene_reset_counters",
     "crt_scene_last_kernel_ms", "crt_scene_last_binning_ms", "crt_strerror", "crt_last_hip_error",
     "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
@@ -222,6 +222,9 @@ def lib():
     L.crt_shadow_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.crt_intersect_batch_dev_noalloc.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.crt_intersect_batch_dev_counted.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.crt_intersect_batch_dev_slice.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, vp]
+    L.crt_shadow_batch_dev_slice.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.crt_scene_reserve_rays.argtypes = [vp, C.c_size_t]
     L.crt_shadow_batch_dev_counted.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.crt_fill_shade_rec.argtypes = [C.POINTER(CrtSceneInput), vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.crt_scene_enable_counters.argtypes = [vp, C.c_int]
@@ -787,6 +790,18 @@ class Scene:
     def intersect_dev_noalloc(self, d_rays, n, d_hits, stream=None):
         """crt_intersect_batch_dev_noalloc: the same on the library's file-scope scratch array (n <= NOALLOC_MAX_RAYS)."""
         _check(lib().crt_intersect_batch_dev_noalloc(self._h, d_rays, n, d_hits, stream), "crt_intersect_batch_dev_noalloc")
+
+    def intersect_dev_slice(self, d_rays, n, d_hits, slice_index, num_slices, stream=None):
+        """crt_intersect_batch_dev_slice: one share (a run of whole binning cells) of a batch several GPUs trace together."""
+        _check(lib().crt_intersect_batch_dev_slice(self._h, d_rays, n, d_hits, int(slice_index), int(num_slices), stream),
+               "crt_intersect_batch_dev_slice")
+
+    def shadow_dev_slice(self, d_rays, d_light_dist, n, d_t, d_occ, slice_index, num_slices, stream=None):
+        _check(lib().crt_shadow_batch_dev_slice(self._h, d_rays, d_light_dist, n, d_t, d_occ, int(slice_index), int(num_slices), stream),
+               "crt_shadow_batch_dev_slice")
+
+    def reserve_rays(self, max_rays):
+        _check(lib().crt_scene_reserve_rays(self._h, int(max_rays)), "crt_scene_reserve_rays")
 
     def shadow_dev(self, d_rays, d_light_dist, n, d_t, d_occ, stream=None):
         _check(lib().crt_shadow_batch_dev(self._h, d_rays, d_light_dist, n, d_t, d_occ, stream), "crt_shadow_batch_dev")

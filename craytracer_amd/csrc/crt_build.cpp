@@ -45,6 +45,8 @@ struct Builder {
     std::vector<int32_t> cell_start, cell_items;
     int max_threads;
 };
+/* four-way tree levels whose children are built by threads of their own: 16 threads, 4, or none */
+static inline int fork_levels(int max_threads) { return max_threads >= 16 ? 2 : (max_threads >= 4 ? 1 : 0); }
 
 /* ---- per-object boxes: getObjectAABB, shapes/shapes.cpp:141-314 ---- */
 
@@ -251,7 +253,7 @@ void build4(Builder& B, NodeCountCache& ncc, int first, int count, int self, int
     }
     B.nodes4[self] = nd;
 
-    bool fork = (depth < 2 && B.max_threads > 1 && count > 65536);
+    bool fork = (depth < fork_levels(B.max_threads) && count > 65536);
     if (fork) {
         std::vector<std::thread> th;
         std::vector<NodeCountCache> caches(4, ncc);
@@ -417,7 +419,7 @@ int build4_sah(Builder& B, std::vector<crt_bvh4_node>& out, int first, int count
         if (cnt > CRT_SAH_LEAF) { nd.type[c] = -1; nd.child[c] = -1; }
         else { nd.type[c] = (int8_t)cnt; nd.child[c] = first + start[c]; }
     }
-    const bool fork = depth < 2 && B.max_threads > 1 && count > 65536;
+    const bool fork = depth < fork_levels(B.max_threads) && count > 65536;
     if (fork) {
         std::vector<std::vector<crt_bvh4_node> > sub(4);
         std::vector<std::thread> th;
@@ -467,7 +469,7 @@ void build2(Builder& B, int first, int count, int self, int depth)
     nd.left = self + 1;
     nd.right = self + 1 + (2 * k - 1);
     B.nodes2[self] = nd;
-    if (depth < 3 && B.max_threads > 1 && count > 65536) {
+    if (depth < 3 && B.max_threads >= 8 && count > 65536) {
         std::thread t([&B, first, k, self, depth]() { build2(B, first, k, self + 1, depth + 1); });
         build2(B, first + k, count - k, nd.right, depth + 1);
         t.join();
@@ -658,6 +660,10 @@ int crt_build_scene_ex(const crt_scene_input* in, int accel, int flags, crt_buil
         B.n = in->num_obj;
         B.max_threads = (int)std::thread::hardware_concurrency();
         if (B.max_threads > 16) B.max_threads = 16;
+        /* one process per GPU: a launcher that starts k ranks on a node gives each its share of the host cores
+         * (bench.py sets CRT_BUILD_THREADS = cores / LOCAL_WORLD_SIZE); the tree does not depend on the thread count */
+        if (const char* e = getenv("CRT_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v < B.max_threads) B.max_threads = v; }
+        if (B.max_threads < 1) B.max_threads = 1;
         B.type.resize(B.n); B.ref.resize(B.n); B.id.resize(B.n); B.box.resize(B.n);
         std::vector<char> gridable(B.n);
         for (int i = 0; i < B.n; i++) {

@@ -50,7 +50,15 @@ struct Scratch {
     unsigned* ovf_word; float* ovf_key; unsigned ovf_threads;   /* per-lane stack overflow, [CRT_OVF_DEPTH][ovf_threads] */
     unsigned* bin_hist; unsigned* bin_cursor;                   /* ray binning: CRT_BIN_CELLS counters each */
     unsigned* perm; size_t perm_cap;                            /* ray order, one word per ray */
+    unsigned short* cells;                                      /* binning cell of every ray (written by the histogram pass, read by the
+                                                                   scatter pass instead of the 24-byte ray records), or null */
 };
+/* A scene owns CRT_SLOTS sets of launch scratch, used in turn: launch k waits (on the device) only for launch k - CRT_SLOTS, the
+ * last one that used ITS set, so two launches enqueued on two streams overlap -- the drain tail of one (its longest rays walking
+ * on alone, about 0.4 ms whatever the batch size) runs beside the start of the next.  On one stream nothing changes. */
+#ifndef CRT_SLOTS
+#define CRT_SLOTS 2
+#endif
 
 /* Events of one launch.  A scene keeps a ring of them so that each caller can ask for the duration of
  * ITS launch (crt_scene_last_kernel_ms) while other threads keep launching through the same scene. */
@@ -79,15 +87,16 @@ struct crt_scene {
     /* device allocations */
     void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
     unsigned long long* d_counters;
-    Scratch own;              /* allocated by crt_scene_create (perm may grow) */
+    Scratch own[CRT_SLOTS];   /* allocated by crt_scene_create (perm / cells may grow); launch k uses own[k % CRT_SLOTS] */
+    unsigned long long slot_last[CRT_SLOTS];   /* launch number (seq) of the last launch through each set, 0 = none yet */
+    unsigned long long own_launches;           /* launches through the own sets so far */
     Scratch na;               /* views into this GPU's copy of the file-scope `scratch` array (crt_intersect_batch_dev_noalloc) */
     LaunchTiming ring[CRT_TIMING_RING]; int ring_valid;   /* events created so far */
     unsigned long long seq;   /* launches so far; launch k uses ring[k % CRT_TIMING_RING] */
     OccEntry occ[CRT_OCC_CACHE]; int n_occ;               /* resident blocks per CU of each kernel, queried once */
-    /* Every launch through this scene uses the one queue head and the one stack-overflow area, so
-     * launches are ordered: a launch waits (on the device) for the previous one's ev_stop even when
-     * it is enqueued on another stream.  The kernels are persistent and fill the GPU, so nothing
-     * is lost by that.  `mu` guards the launch sequence and the events against concurrent callers. */
+    /* A launch uses one of the scene's scratch sets (queue head, ray order, stack overflow) and waits, on the device,
+     * for the launch that used that set before it, even when it is enqueued on another stream (see CRT_SLOTS).
+     * `mu` guards the launch sequence and the events against concurrent callers. */
     std::mutex mu;
     /* host-buffer entry points: two chunk-sized device buffers and two streams, created on first use */
     void* d_chunk_in[2]; void* d_chunk_aux[2]; void* d_chunk_out[2]; void* d_chunk_out2[2];
@@ -416,9 +425,12 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist, s->d_cell_objs,
-                     s->d_bnodes2, s->d_bnodes2w, s->d_counters, s->own.queue_head, s->own.ovf_word, s->own.ovf_key,
-                     s->own.bin_hist, s->own.bin_cursor, s->own.perm };
+                     s->d_bnodes2, s->d_bnodes2w, s->d_counters };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < CRT_SLOTS; k++) {
+        void* q[] = { s->own[k].queue_head, s->own[k].ovf_word, s->own[k].ovf_key, s->own[k].bin_hist, s->own[k].bin_cursor, s->own[k].perm, s->own[k].cells };
+        for (void* p : q) if (p) (void)hipFree(p);
+    }
     for (int k = 0; k < 2; k++) {
         void* q[] = { s->d_chunk_in[k], s->d_chunk_aux[k], s->d_chunk_out[k], s->d_chunk_out2[k] };
         for (void* p : q) if (p) (void)hipFree(p);
@@ -443,7 +455,7 @@ void free_scene(crt_scene* s)
  *   [.., +2 x CRT_NA_THREADS * CRT_OVF_DEPTH * 4)   per-lane stack overflow (words, keys)
  * = 64 MiB + 33 024 B. */
 #define CRT_NA_MAX_RAYS  CRT_NOALLOC_MAX_RAYS         /* include/crt_gpu.h: 2^22 */
-#define CRT_NA_THREADS   (512u * CRT_BLOCK)               /* 512 resident blocks: 2 per CU on 256 CUs */
+#define CRT_NA_THREADS   (512u * 256u)                    /* 512 resident 256-thread blocks: 2 per CU on 256 CUs */
 #define CRT_NA_OFF_HIST  256u
 #define CRT_NA_OFF_CURS  (CRT_NA_OFF_HIST + CRT_BIN_CELLS * 4u)
 #define CRT_NA_OFF_PERM  (CRT_NA_OFF_CURS + CRT_BIN_CELLS * 4u)
@@ -456,6 +468,12 @@ static __device__ __align__(256) unsigned char scratch[CRT_NA_BYTES];
 #define CRT_MAX_DEVICES 64
 std::mutex g_na_mu;
 unsigned char* g_na_ptr[CRT_MAX_DEVICES];                  /* per device: address of ITS copy of `scratch` */
+/* Every no-allocation launch on a GPU shares that GPU's array, whichever scene it comes through, so such launches are ordered
+ * per DEVICE: each waits (on the device) for the event the one before it recorded.  One library-owned event per device, created
+ * with the address above at scene creation -- the entry point itself still creates nothing.  g_na_mu is held from the wait to
+ * the record, so two threads launching through two scenes cannot interleave their enqueues. */
+hipEvent_t g_na_ev[CRT_MAX_DEVICES];
+bool g_na_ev_recorded[CRT_MAX_DEVICES];
 std::atomic<unsigned long long> g_scene_uid(0);
 
 /* call with `device` current */
@@ -466,6 +484,10 @@ int resolve_noalloc_scratch(int device, Scratch* out)
     if (!g_na_ptr[device]) {
         void* ptr = 0;
         if (!hip_ok(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !ptr) return CRT_E_HIP;
+        hipEvent_t ev;
+        if (!hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) return CRT_E_HIP;
+        g_na_ev[device] = ev;
+        g_na_ev_recorded[device] = false;
         g_na_ptr[device] = (unsigned char*)ptr;
     }
     unsigned char* base = g_na_ptr[device];
@@ -474,6 +496,7 @@ int resolve_noalloc_scratch(int device, Scratch* out)
     out->bin_cursor = (unsigned*)(base + CRT_NA_OFF_CURS);
     out->perm = (unsigned*)(base + CRT_NA_OFF_PERM);
     out->perm_cap = CRT_NA_MAX_RAYS;
+    out->cells = 0;                                    /* the scatter pass reads the ray records again */
     out->ovf_word = (unsigned*)(base + CRT_NA_OFF_OVFW);
     out->ovf_key = (float*)(base + CRT_NA_OFF_OVFK);
     out->ovf_threads = CRT_NA_THREADS;
@@ -486,6 +509,7 @@ thread_local unsigned long long tl_scene_uid = 0, tl_seq = 0;
 /* ---- launch ------------------------------------------------------------------------- */
 
 const unsigned CRT_BIN_MIN_RAYS = 1u << 18;
+#define CRT_QUEUE_RANGE_WORD 32                        /* words 32..35 of the 256-byte queue-head line: a slice launch's range[] (BinSlice) */
 const size_t CRT_PERM_PRESIZE = (size_t)1 << 24;      /* 64 MB: ray order for batches up to 2^24 rays, allocated with the scene */
 /* The walks saturate at 4 resident blocks (waves per SIMD) per CU: 691 / 936 / 1 090 / 1 092 Mrays/s at 2 / 3 / 4 / 5
  * (closest hit, courtyard-10M); the any-hit walk, whose 16 KB stack would allow 7, runs 1 904 at 5 against 1 869 at 7. */
@@ -497,13 +521,32 @@ const int CRT_MAX_BLOCKS_PER_CU = CRT_MAX_BLOCKS;
 #define CRT_GRID_BLOCKS 8          /* the grid walk has no LDS stack and waits on dependent fetches: all the waves its registers allow */
 #endif
 
-/* NOALLOC: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
- * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before. */
-template <class K>
-int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_binning = false, bool noalloc = false, int max_blocks = CRT_MAX_BLOCKS_PER_CU)
+/* How a launch is made.  noalloc: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
+ * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before
+ * (crt_scene_reserve_rays sizes it ahead).  slice_count > 0: only slice `slice` of the batch is walked (see BinSlice). */
+struct LaunchOpts {
+    bool use_binning; bool noalloc; int max_blocks; unsigned slice, slice_count;
+    LaunchOpts(bool bin = false, bool na = false, int mb = CRT_MAX_BLOCKS_PER_CU) : use_binning(bin), noalloc(na), max_blocks(mb), slice(0), slice_count(0) {}
+};
+
+int grow_perm(Scratch& sx, size_t n, hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lock(s->mu);
-    Scratch& sx = noalloc ? s->na : s->own;
+    if (n <= sx.perm_cap) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(stream));     /* grows only; the previous launch has been waited for */
+    if (sx.perm) { (void)hipFree(sx.perm); sx.perm = 0; sx.perm_cap = 0; }
+    if (sx.cells) { (void)hipFree(sx.cells); sx.cells = 0; }
+    if (!hip_ok(hipMalloc((void**)&sx.perm, n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
+    if (!hip_ok(hipMalloc((void**)&sx.cells, n * sizeof(unsigned short)), "hipMalloc")) { (void)hipFree(sx.perm); sx.perm = 0; return CRT_E_NOMEM; }
+    sx.perm_cap = n;
+    return CRT_OK;
+}
+
+template <class K>
+int launch_locked(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, const LaunchOpts& o)
+{
+    const bool noalloc = o.noalloc;
+    const int slot = (int)(s->own_launches % CRT_SLOTS);
+    Scratch& sx = noalloc ? s->na : s->own[slot];
     int per_cu = 0;
     for (int k = 0; k < s->n_occ; k++) if (s->occ[k].fn == (const void*)kernel) per_cu = s->occ[k].per_cu;
     if (per_cu == 0) {                                  /* once per kernel and scene, not once per launch */
@@ -511,9 +554,18 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
         if (per_cu < 1) per_cu = 1;
         if (s->n_occ < CRT_OCC_CACHE) { s->occ[s->n_occ].fn = (const void*)kernel; s->occ[s->n_occ].per_cu = per_cu; s->n_occ++; }
     }
-    if (per_cu > max_blocks) per_cu = max_blocks;
+    if (per_cu > o.max_blocks * (256 / CRT_BLOCK)) per_cu = o.max_blocks * (256 / CRT_BLOCK);      /* max_blocks counts 256-thread blocks */
     unsigned blocks = (unsigned)(s->num_cus * per_cu);
-    unsigned need = (la.n + CRT_BLOCK - 1) / CRT_BLOCK;
+    const bool bin = o.use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
+    /* a slice of a batch that is not binned is a slice by ray index */
+    unsigned walk_n = la.n;
+    la.q_first = 0; la.q_range = 0;
+    if (o.slice_count > 0 && !bin) {
+        la.q_first = (unsigned)((unsigned long long)la.n * o.slice / o.slice_count);
+        la.n = (unsigned)((unsigned long long)la.n * (o.slice + 1u) / o.slice_count);
+        walk_n = la.n - la.q_first;
+    } else if (o.slice_count > 0) walk_n = la.n / o.slice_count + 1u;                 /* about that many; the kernels read the range */
+    unsigned need = (walk_n + CRT_BLOCK - 1) / CRT_BLOCK;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     if (blocks * CRT_BLOCK > sx.ovf_threads) blocks = sx.ovf_threads / CRT_BLOCK;   /* overflow area is sized for this many */
@@ -522,8 +574,9 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
     la.ovf_key = sx.ovf_key;
     la.grid_threads = sx.ovf_threads;
     LaunchTiming& lt = s->ring[s->seq % CRT_TIMING_RING];
-    if (s->seq > 0) HIPCHK(hipStreamWaitEvent(stream, s->ring[(s->seq - 1) % CRT_TIMING_RING].ev_stop, 0));   /* shared scratch: see crt_scene */
-    const bool bin = use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
+    /* the launch that used this scratch before (CRT_SLOTS launches ago: its ring entry is still its own) */
+    if (!noalloc && s->slot_last[slot] > 0) HIPCHK(hipStreamWaitEvent(stream, s->ring[(s->slot_last[slot] - 1) % CRT_TIMING_RING].ev_stop, 0));
+    if (noalloc && g_na_ev_recorded[s->device]) HIPCHK(hipStreamWaitEvent(stream, g_na_ev[s->device], 0));    /* see g_na_ev */
     /* what must start at zero: the queue head, and (the binning kernels leave it zeroed, but a launch that
      * failed half way may not have) the histogram behind it in the file-scope array */
     if (noalloc) HIPCHK(hipMemsetAsync(sx.queue_head, 0, CRT_NA_OFF_CURS, stream));
@@ -532,67 +585,91 @@ int launch(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, bool use_b
     if (bin) {
         if (la.n > sx.perm_cap) {
             if (noalloc) return CRT_E_TOOBIG;
-            HIPCHK(hipStreamSynchronize(stream));     /* grows only; the previous launch has been waited for above */
-            if (sx.perm) { (void)hipFree(sx.perm); sx.perm = 0; sx.perm_cap = 0; }
-            if (!hip_ok(hipMalloc((void**)&sx.perm, (size_t)la.n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
-            sx.perm_cap = la.n;
+            const int rc = grow_perm(sx, la.n, stream);
+            if (rc != CRT_OK) return rc;
         }
         HIPCHK(hipEventRecord(lt.ev_bin, stream));
         const unsigned bb = (la.n + CRT_BIN_CHUNK - 1) / CRT_BIN_CHUNK;
-        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_hist);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, sx.bin_hist, sx.bin_cursor);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_cursor, sx.perm);
+        BinSlice sl; sl.k = o.slice; sl.count = o.slice_count;
+        unsigned* range = o.slice_count > 0 ? sx.queue_head + CRT_QUEUE_RANGE_WORD : (unsigned*)0;
+        hipLaunchKernelGGL(k_bin_hist, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_hist, sx.cells);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(CRT_BIN_BLOCK), 0, stream, sx.bin_hist, sx.bin_cursor, sl, range);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(bb), dim3(CRT_BIN_BLOCK), 0, stream, la.rays, la.n, la.n_dev, s->bin_grid, sx.bin_cursor, sx.perm,
+                           (const unsigned*)range, (const unsigned short*)sx.cells);
         HIPCHK(hipGetLastError());
         la.perm = sx.perm;
+        la.q_range = range;
     }
     HIPCHK(hipEventRecord(lt.ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(lt.ev_stop, stream));
+    if (noalloc) { HIPCHK(hipEventRecord(g_na_ev[s->device], stream)); g_na_ev_recorded[s->device] = true; }
     lt.binned = bin;
     lt.seq = ++s->seq;
+    if (!noalloc) { s->slot_last[slot] = lt.seq; s->own_launches++; }
     tl_scene_uid = s->uid; tl_seq = lt.seq;
     return CRT_OK;
 }
 
+template <class K>
+int launch(crt_scene* s, K kernel, const LaunchArgs& la, hipStream_t stream, const LaunchOpts& o)
+{
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!o.noalloc) return launch_locked(s, kernel, la, stream, o);
+    std::lock_guard<std::mutex> lock_dev(g_na_mu);            /* lock order: scene, then device */
+    return launch_locked(s, kernel, la, stream, o);
+}
+
 template <bool TRI_ONLY, bool COUNT>
-int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, bool na = false)
+int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, LaunchOpts o = LaunchOpts())
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
+    const bool na = o.noalloc;
+    o.use_binning = true; o.max_blocks = CRT_MAX_BLOCKS_PER_CU;
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: if (TRI_ONLY && !exact && s->compress && s->cnodes_valid && s->dev.num_obj > 0) {
                              /* small batches: the walk whose idle lanes take pending subtrees from busy ones once the queue is dry
-                              * (crt_kernels.h, "tail splitting").  Not for counted launches (n is an upper bound there) nor for the
-                              * no-allocation entry point (its overflow area is sized for the 14-entry LDS stack). */
-                             if (!na && !la.n_dev && la.n <= s->split_max_rays) return launch(s, k_bvh4_closest_tri<COUNT, true>, la, st, true, na);
-                             return launch(s, k_bvh4_closest_tri<COUNT>, la, st, true, na);
+                              * (crt_kernels.h, "tail splitting").  For a counted launch n is an upper bound, for a slice the share is
+                              * about n / slices.  Not for the no-allocation entry point (its overflow area is sized for the 14-entry
+                              * LDS stack), and not when objects wait outside the tree: a split ray is settled without the non-grid
+                              * loop of intersect.h:403-411. */
+                             const unsigned share = o.slice_count > 0 ? la.n / o.slice_count : la.n;
+                             if (!na && s->dev.nng == 0 && share <= s->split_max_rays) return launch(s, k_bvh4_closest_tri<COUNT, true>, la, st, o);
+                             return launch(s, k_bvh4_closest_tri<COUNT>, la, st, o);
                          }
-                         return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, true, na)
-                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, true, na);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true>, la, st, true, na);
-                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, true, na);
-                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, true, na)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, true, na);
+                         return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, o)
+                                      : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, o);
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true>, la, st, o);
+                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, o);
+                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, o)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, o);
     case CRT_ACCEL_GRID: /* lane refill pays for incoherent closest-hit rays through triangles (735 -> 1 229 Mrays/s); the any-hit walk
                             (694 plain, 637 with refill) and the all-shapes instance (C1: 7.1 against 8.7 ms) keep the plain loop */
-                         if constexpr (TRI_ONLY) return launch(s, k_grid_refill<true, COUNT, false>, la, st, true, na, CRT_GRID_BLOCKS);
-                         else return launch(s, k_grid<false, COUNT, false>, la, st, true, na, CRT_GRID_BLOCKS);
-    default:             return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, false, na);
+                         o.max_blocks = CRT_GRID_BLOCKS;
+                         if constexpr (TRI_ONLY) return launch(s, k_grid_refill<true, COUNT, false>, la, st, o);
+                         else return launch(s, k_grid<false, COUNT, false>, la, st, o);
+    default:             o.use_binning = false;
+                         return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, o);
     }
 }
 template <bool TRI_ONLY, bool COUNT>
-int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st)
+int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st, unsigned slice = 0, unsigned slice_count = 0)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
+    LaunchOpts o(true);
+    o.slice = slice; o.slice_count = slice_count;
     switch (s->dev.accel) {
-    case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, true);
-                         return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, true);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true>, la, st, true);
-                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, true);
-                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, true)
-                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, true);
-    case CRT_ACCEL_GRID: return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st, true, false, CRT_GRID_BLOCKS);
-    default:             return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st);
+    case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, o);
+                         return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, o);
+    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true>, la, st, o);
+                         if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, o);
+                         return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, o)
+                                      : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, o);
+    case CRT_ACCEL_GRID: o.max_blocks = CRT_GRID_BLOCKS;
+                         return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st, o);
+    default:             o.use_binning = false;
+                         return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st, o);
     }
 }
 
@@ -877,22 +954,26 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     int cus = 0;
     if (!hip_ok(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute")) { free_scene(s); return CRT_E_HIP; }
     s->num_cus = cus > 0 ? cus : 1;
-    s->own.ovf_threads = (unsigned)s->num_cus * 8u * CRT_BLOCK;       /* at most 8 resident 256-thread blocks per CU */
-    size_t ovf_bytes = (size_t)s->own.ovf_threads * (CRT_OVF_DEPTH + 1) * sizeof(unsigned);    /* + 1: the tail-splitting walk keeps one entry fewer in LDS */
-    if (!hip_ok(hipMalloc((void**)&s->own.ovf_word, ovf_bytes), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->own.ovf_key, ovf_bytes), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->own.queue_head, 256), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->own.bin_hist, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void**)&s->own.bin_cursor, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
-    if (s->bin_grid_valid) {
-        /* ray order sized ahead for the batches the binning is meant for, so that the launch path neither allocates
-         * nor synchronises; a larger batch still grows it (launch()) */
-        s->own.perm_cap = CRT_PERM_PRESIZE;
-        if (!hip_ok(hipMalloc((void**)&s->own.perm, s->own.perm_cap * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    for (int k = 0; k < CRT_SLOTS; k++) {
+        Scratch& sx = s->own[k];
+        sx.ovf_threads = (unsigned)s->num_cus * 8u * 256u;            /* at most 8 resident 256-thread blocks (2 048 threads) per CU */
+        size_t ovf_bytes = (size_t)sx.ovf_threads * (CRT_OVF_DEPTH + 1) * sizeof(unsigned);    /* + 1: the tail-splitting walk keeps one entry fewer in LDS */
+        if (!hip_ok(hipMalloc((void**)&sx.ovf_word, ovf_bytes), "hipMalloc") ||
+            !hip_ok(hipMalloc((void**)&sx.ovf_key, ovf_bytes), "hipMalloc") ||
+            !hip_ok(hipMalloc((void**)&sx.queue_head, 256), "hipMalloc") ||
+            !hip_ok(hipMalloc((void**)&sx.bin_hist, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc") ||
+            !hip_ok(hipMalloc((void**)&sx.bin_cursor, CRT_BIN_CELLS * sizeof(unsigned)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+        if (s->bin_grid_valid) {
+            /* ray order sized ahead for the batches the binning is meant for, so that the launch path neither allocates
+             * nor synchronises; a larger batch still grows it (launch(); crt_scene_reserve_rays does it ahead of time) */
+            sx.perm_cap = CRT_PERM_PRESIZE;
+            if (!hip_ok(hipMalloc((void**)&sx.perm, sx.perm_cap * sizeof(unsigned)), "hipMalloc") ||
+                !hip_ok(hipMalloc((void**)&sx.cells, sx.perm_cap * sizeof(unsigned short)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+        }
+        if (!hip_ok(hipMemset(sx.bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     }
-    if (!hip_ok(hipMemset(s->own.bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset") ||
-        !hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
+    if (!hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+    if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     for (int k = 0; k < CRT_TIMING_RING; k++) {
         LaunchTiming& lt = s->ring[k];
         if (!hip_ok(hipEventCreate(&lt.ev_bin), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
@@ -1020,7 +1101,8 @@ int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
     return CRT_OK;
 }
 
-static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc, const uint32_t* d_n = 0)
+static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc, const uint32_t* d_n = 0,
+                         unsigned slice = 0, unsigned slice_count = 0)
 {
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -1032,8 +1114,10 @@ static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit*
     memset(&la, 0, sizeof la);
     la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
-    if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st, noalloc) : dispatch_closest<true, false>(s, la, st, noalloc);
-    return s->count ? dispatch_closest<false, true>(s, la, st, noalloc) : dispatch_closest<false, false>(s, la, st, noalloc);
+    LaunchOpts o(true, noalloc);
+    o.slice = slice; o.slice_count = slice_count;
+    if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st, o) : dispatch_closest<true, false>(s, la, st, o);
+    return s->count ? dispatch_closest<false, true>(s, la, st, o) : dispatch_closest<false, false>(s, la, st, o);
 }
 
 int crt_intersect_batch_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream)
@@ -1047,6 +1131,33 @@ int crt_intersect_batch_dev_noalloc(crt_scene* s, const crt_ray* d_rays, size_t 
     return intersect_dev(s, d_rays, n, d_hits, stream, true);
 }
 
+/* One share of a batch that k GPUs (or k launches) trace together: slice `slice` of `num_slices`.  With ray binning the whole
+ * batch is binned and the share is a run of whole Morton cells holding about n / num_slices rays (BinSlice, crt_binning.h): each
+ * share touches its own piece of the scene with the batch's full ray density per cell.  Without binning (no accelerator, binning
+ * switched off, fewer than 2^18 rays) the share is the index range [n k / K, n (k + 1) / K).  Either way the shares of the K
+ * slices tile the batch exactly, and each hit lands at its ray's own index in d_hits; records of other shares are not touched. */
+int crt_intersect_batch_dev_slice(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, uint32_t slice, uint32_t num_slices, void* stream)
+{
+    if (num_slices < 1 || slice >= num_slices || num_slices > 65536u) return CRT_E_INVALID;
+    return intersect_dev(s, d_rays, n, d_hits, stream, false, 0, slice, num_slices);
+}
+
+/* Sizes the scene's launch scratch for batches of up to max_rays rays ahead of time, so that no later launch allocates or
+ * synchronises (the ray-order buffer is created for 2^24 rays and otherwise grows, with a stream synchronise, inside the first
+ * launch of a larger batch). */
+int crt_scene_reserve_rays(crt_scene* s, size_t max_rays)
+{
+    if (!s) return CRT_E_INVALID;
+    if (max_rays > 0xF0000000u) return CRT_E_TOOBIG;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return CRT_E_HIP;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->bin_grid_valid) return CRT_OK;                       /* this scene's launches use no ray order */
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < CRT_SLOTS; k++) { const int rc = grow_perm(s->own[k], max_rays, 0); if (rc != CRT_OK) return rc; }
+    return CRT_OK;
+}
+
 /* Counted launches: the number of rays is read from device memory by the kernels themselves (*d_n, at most n_max), so a
  * wavefront driver can chain extend -> shade -> shadow launches without the host ever learning the queue sizes. */
 int crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const uint32_t* d_n, size_t n_max, crt_hit* d_hits, void* stream)
@@ -1056,7 +1167,7 @@ int crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const u
 }
 
 static int shadow_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
-                      float* d_t_out, uint8_t* d_occluded_out, void* stream, const uint32_t* d_n)
+                      float* d_t_out, uint8_t* d_occluded_out, void* stream, const uint32_t* d_n, unsigned slice = 0, unsigned slice_count = 0)
 {
     if (!s || (n > 0 && (!d_rays || !d_light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -1067,8 +1178,14 @@ static int shadow_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_
     memset(&la, 0, sizeof la);
     la.rays = d_rays; la.light_dist = d_light_dist; la.t_out = d_t_out; la.occ_out = d_occluded_out; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
-    if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st) : dispatch_shadow<true, false>(s, la, st);
-    return s->count ? dispatch_shadow<false, true>(s, la, st) : dispatch_shadow<false, false>(s, la, st);
+    if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st, slice, slice_count) : dispatch_shadow<true, false>(s, la, st, slice, slice_count);
+    return s->count ? dispatch_shadow<false, true>(s, la, st, slice, slice_count) : dispatch_shadow<false, false>(s, la, st, slice, slice_count);
+}
+int crt_shadow_batch_dev_slice(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                               float* d_t_out, uint8_t* d_occluded_out, uint32_t slice, uint32_t num_slices, void* stream)
+{
+    if (num_slices < 1 || slice >= num_slices || num_slices > 65536u) return CRT_E_INVALID;
+    return shadow_dev(s, d_rays, d_light_dist, n, d_t_out, d_occluded_out, stream, 0, slice, num_slices);
 }
 int crt_shadow_batch_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                          float* d_t_out, uint8_t* d_occluded_out, void* stream)

@@ -12,7 +12,9 @@
 #pragma once
 #include "crt_device.h"
 
-#define CRT_BLOCK      256
+#ifndef CRT_BLOCK
+#define CRT_BLOCK      256         /* threads per workgroup of the walk kernels (a multiple of 64 that divides 256) */
+#endif
 /* LDS part of the per-lane stack.  8-byte entries (closest-hit walks): 14 deep = 28 KB per workgroup, so that FIVE workgroups
  * are resident per CU -- at 16 deep (32 KB) only four fit in the 160 KB, and the fifth wave per SIMD is worth 8 % (1 813 ->
  * 1 954 Mrays/s; 12 deep: 1 915, six waves at 80 VGPRs and 12 / 13 deep: 1 844 / 1 854).  4-byte entries (any-hit walks): 16 deep. */
@@ -43,11 +45,19 @@ struct LaunchArgs {
     unsigned grid_threads;
     const unsigned* perm;         /* queue slot -> ray index (crt_binning.h), or null: slot == ray index */
     const unsigned* n_dev;        /* counted launches: the ray count lives on the device (n is then its upper bound), or null */
+    const unsigned* q_range;      /* slice launches (crt_intersect_batch_dev_slice): {first, end} queue slot of this launch's share of the
+                                     binned batch, written by k_bin_scan; or null: the whole queue */
+    unsigned q_first;             /* first queue slot of the launch (0 unless q_range, or a slice by ray index) */
 };
-/* first statement of every walk kernel: the launch's ray count */
+/* first statement of every walk kernel: the launch's ray count and the part of the queue it walks, [q_first, n) */
 CRT_DEV void resolve_count(LaunchArgs& la)
 {
     if (la.n_dev) { const unsigned m = *la.n_dev; la.n = m < la.n ? m : la.n; }
+    if (la.q_range) {
+        const unsigned lo = la.q_range[0], hi = la.q_range[1];
+        la.n = hi < la.n ? hi : la.n;
+        la.q_first = lo < la.n ? lo : la.n;
+    }
 }
 
 /* ---- per-lane stack ----------------------------------------------------------------
@@ -134,12 +144,12 @@ CRT_DEV void store_hit(crt_hit* hits, unsigned i, float t, const DHit& h)
     hits[i] = o;
 }
 
-/* Wave-level fetch of the next 64 rays. */
-CRT_DEV unsigned next_batch(unsigned* queue_head)
+/* Wave-level fetch of the next 64 queue slots. */
+CRT_DEV unsigned next_batch(const LaunchArgs& la)
 {
     unsigned base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(queue_head, 64u);
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(la.queue_head, 64u);
+    return la.q_first + (unsigned)__builtin_amdgcn_readfirstlane((int)base);
 }
 
 template <bool COUNT>
@@ -349,9 +359,6 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #else
 #define CRT_WALK_WAVES
 #endif
-#ifndef CRT_XCD_RANGES
-#define CRT_XCD_RANGES 0
-#endif
 #ifndef CRT_FUSE_LEAF_SHADOW
 #define CRT_FUSE_LEAF_SHADOW 1    /* the same in the any-hit walk: +3.6 % */
 #endif
@@ -391,41 +398,12 @@ struct RayFeed {
     unsigned res_pos, res_cnt;        /* wave-uniform: next unread slot / slots in the current claim */
     bool empty;                       /* wave-uniform: the queue has nothing more for this wave */
     unsigned pre_ri; DRay pre_ray; float pre_ld;
-#if CRT_XCD_RANGES
-    /* The queue (in the binning step's order: pieces of space) is cut into 8 contiguous ranges with one head each (8 words 32
-     * bytes apart in the queue-head line).  A wave starts in the range of its workgroup's XCD (workgroups are dealt to the 8
-     * XCDs round-robin) and moves to the next range when its own is drained, so each XCD's L2 mostly serves one piece of the
-     * scene; which wave traces a ray changes nothing about the ray's result. */
-    unsigned rng, adv, rng_len;       /* wave-uniform: current range, ranges found drained so far, slots per range (multiple of 64) */
-    CRT_DEV void claim(const LaunchArgs& la)
-    {
-        if ((threadIdx.x & 63) == 0) pend = atomicAdd(la.queue_head + rng * 8u, 64u);
-    }
-    CRT_DEV unsigned claimed_base(const LaunchArgs& la)      /* slot index of the claim in `pend`, or la.n when everything is drained */
-    {
-        for (;;) {
-            const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend);
-            const unsigned beg = rng * rng_len;
-            const unsigned end = beg + rng_len < la.n ? beg + rng_len : la.n;
-            if (beg < la.n && off < end - beg) return beg + off;
-            if (++adv >= 8u) return la.n;
-            rng = (rng + 1u) & 7u;
-            claim(la);
-        }
-    }
-    CRT_DEV unsigned claim_limit(const LaunchArgs& la, unsigned base)
-    {
-        const unsigned end = rng * rng_len + rng_len < la.n ? rng * rng_len + rng_len : la.n;
-        return end - base;
-    }
-#else
     CRT_DEV void claim(const LaunchArgs& la)
     {
         if ((threadIdx.x & 63) == 0) pend = atomicAdd(la.queue_head, 64u);
     }
-    CRT_DEV unsigned claimed_base(const LaunchArgs& la) { return (unsigned)__builtin_amdgcn_readfirstlane((int)pend); }
+    CRT_DEV unsigned claimed_base(const LaunchArgs& la) { return la.q_first + (unsigned)__builtin_amdgcn_readfirstlane((int)pend); }
     CRT_DEV unsigned claim_limit(const LaunchArgs& la, unsigned base) { return la.n - base; }
-#endif
     CRT_DEV void swap_in(const LaunchArgs& la)
     {
         const unsigned base = claimed_base(la);
@@ -445,10 +423,6 @@ struct RayFeed {
     CRT_DEV void start(const LaunchArgs& la)
     {
         pend = 0; res_pos = res_cnt = 0; empty = false;
-#if CRT_XCD_RANGES
-        rng = blockIdx.x & 7u; adv = 0u;
-        rng_len = (((la.n + 7u) >> 3) + 63u) & ~63u;
-#endif
         pre_ri = 0; pre_ld = 0.0f;
         pre_ray.ox = pre_ray.oy = pre_ray.oz = 0.0f; pre_ray.dx = pre_ray.dy = pre_ray.dz = 1.0f;
         claim(la);
@@ -1059,7 +1033,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_closest(DevScene sc, LaunchA
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_prims = 0;
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
+        const unsigned base = next_batch(la);
         if (base >= la.n) break;
         const unsigned ri = base + lane;
         if (ri < la.n) {
@@ -1080,7 +1054,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_prims = 0;
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
+        const unsigned base = next_batch(la);
         if (base >= la.n) break;
         const unsigned ri = base + lane;
         if (ri < la.n) {
@@ -1319,7 +1293,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
     const unsigned lane = threadIdx.x & 63;
     unsigned c_rays = 0, c_nodes = 0, c_prims = 0;
     for (;;) {
-        const unsigned base = next_batch(la.queue_head);
+        const unsigned base = next_batch(la);
         if (base >= la.n) break;
         const unsigned slot = base + lane;
         if (slot < la.n) {

@@ -273,17 +273,34 @@ int  crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const 
 int  crt_shadow_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, const uint32_t* d_n, size_t n_max,
                                   float* d_t_out, uint8_t* d_occluded_out, void* stream);
 
+/* One share of a batch traced by several GPUs (or launches) together.  Replaces main.cpp:276-317, where the reference cuts a
+ * sample pass into `num_patches` pixel ranges for its worker threads: slice `slice` of `num_slices`.  The whole batch is binned
+ * (a counting sort of the ray indices by the cell of the ray origin) and the share is a run of whole cells holding about
+ * n / num_slices rays, so each GPU touches its own piece of the scene at the batch's full ray density.  The cut points depend on
+ * the cell counts only: K processes that hold the same batch on K GPUs and pass slice = 0 .. K - 1 tile it exactly, each ray
+ * traced once.  Hits land at the rays' own indices in d_hits; the records of other shares are not written.  A batch that is
+ * not binned (no accelerator, fewer than 2^18 rays, binning switched off) is cut by ray index, [n k / K, n (k + 1) / K). */
+int  crt_intersect_batch_dev_slice(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, uint32_t slice, uint32_t num_slices, void* stream);
+int  crt_shadow_batch_dev_slice(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
+                                float* d_t_out, uint8_t* d_occluded_out, uint32_t slice, uint32_t num_slices, void* stream);
+
+/* Sizes the scene's launch scratch for batches of up to max_rays rays, so that no later launch allocates or synchronises.  (The
+ * ray-order buffer of the binning step is created for 2^24 rays; the first launch of a larger batch otherwise grows it, which
+ * costs a stream synchronise, a hipFree and a hipMalloc inside that launch.)  No counterpart in the reference. */
+int  crt_scene_reserve_rays(crt_scene* s, size_t max_rays);
+
 /* crt_intersect_batch_dev for callers that cannot allocate.  No counterpart in the reference: it exists for
- * callers that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid
- * allocation.  Same kernels, same results bit for bit; the device memory they need beyond d_rays / d_hits (queue
+ * callers that may not call hipMalloc -- tight serving loops, harnesses that forbid allocation.  (The launch is not made for HIP
+ * graph capture: it records and waits on the library's own events and reads them back for crt_scene_last_kernel_ms.)
+ * Same kernels, same results bit for bit; the device memory they need beyond d_rays / d_hits (queue
  * head, ray order of the binning step, per-lane stack overflow) is one file-scope device array of
  * CRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, instead of the
  * scene's own buffers.  The call performs no hipMalloc / hipFree / allocating library call.
  *   n > CRT_NOALLOC_MAX_RAYS              -> CRT_E_TOOBIG
  *   resident grid capped at 512 workgroups (the overflow part of the array is sized for that many)
- * Calls through ONE crt_scene are ordered by the library like crt_intersect_batch_dev's.  All scenes on a GPU share
- * that GPU's array (within a process): calls through DIFFERENT scenes that overlap in time on one GPU race on
- * it -- the caller orders them. */
+ * All scenes on a GPU share that GPU's array (within a process), so the library orders these calls per DEVICE: each waits, on
+ * the device, for the no-allocation launch enqueued before it, whichever scene and stream that one went through (one
+ * library-owned event per device, created at scene creation).  Two processes on one GPU hold two arrays. */
 #define CRT_NOALLOC_MAX_RAYS      (1u << 22)
 #define CRT_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u + 33024u)
 int  crt_intersect_batch_dev_noalloc(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream);

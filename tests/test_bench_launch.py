@@ -83,3 +83,24 @@ def test_world_size_must_match_gpus():
 def test_a_failing_rank_fails_the_launcher():
     p2 = run(["--gpus", "2", "--dry-backend", "gloo", "--workload", "no-such-workload"])
     assert p2.returncode != 0
+
+
+def test_a_rank_that_dies_mid_run_stops_the_others_within_seconds():
+    """Rank 1 exits after the timed steps while rank 0 waits in the barrier: without supervision rank 0 would sit there
+    until the process-group timeout (minutes).  The launcher must stop it and exit non-zero with every return code."""
+    import time
+    t0 = time.time()
+    p = run(["--gpus", "2", "--dry-backend", "gloo", "--steps", "1", "--rays", "100"],
+            env={"BENCH_DRY_DIE_RANK": "1", "BENCH_DRY_DIE_CODE": "7"}, timeout=120)
+    dt = time.time() - t0
+    assert p.returncode != 0
+    assert "rank 1 exited with code 7" in p.stderr and "rank exit codes" in p.stderr, p.stderr[-2000:]
+    assert dt < 60, "the launcher waited %.0f s for a rank that was never going to finish" % dt
+    assert json_lines(p) == []                                    # no result line from a run that lost a rank
+
+
+def test_the_launcher_gives_up_at_its_own_deadline():
+    """All ranks alive but never finishing (rank 1 dies SILENTLY is covered above; here rank 0 is the one that dies, with
+    code 0 masked as success being impossible -- so instead: a deadline of one second on a run that needs longer)."""
+    p = run(["--gpus", "2", "--dry-backend", "gloo", "--steps", "4000", "--rays", "100"], env={"BENCH_LAUNCH_TIMEOUT": "1"}, timeout=120)
+    assert p.returncode != 0 and "BENCH_LAUNCH_TIMEOUT reached" in p.stderr, p.stderr[-2000:]

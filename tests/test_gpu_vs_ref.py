@@ -1,0 +1,73 @@
+"""The HIP path against the REFERENCE ITSELF, run on the GPU box: oracle/_ref/libcrt_ref.so is the reference's own
+BVH4_build / BVH4IntersectTest / BVH4ShadowIntersectTest / rayIntersectObject (accelerator/bvh4.h, shapes/*.cpp), compiled in the
+build container from the sources where they lie (oracle/Makefile: ref) and shipped with the tree like every built library --
+which is why oracle/_ref is git-ignored but NOT gpurun-ignored.  Nothing here reads /root/reference.
+
+The other GPU tests compare the kernels with the restatement (oracle/), and the restatement with this library in the build
+container; this file closes the triangle on the box, without the restatement in between, at sizes the -O0 reference finishes in
+seconds.  Skipped where the library is absent (a tree that was never built where /root/reference exists)."""
+import numpy as np
+import pytest
+
+from craytracer_amd import api, scenes
+import oraclelib as ol
+
+pytestmark = [pytest.mark.gpu, pytest.mark.ref]
+
+
+def _rays(si, n, seed):
+    lo, hi = scenes.scene_bounds(si)
+    pad = (hi - lo) * 0.1
+    r = scenes.random_rays(n, lo - pad, hi + pad, seed)
+    ld = (np.random.default_rng(seed).random(n) * np.linalg.norm(hi - lo)).astype(np.float32)
+    return r, ld
+
+
+@pytest.mark.parametrize("scene", ["soup20k", "blobs66k"])
+def test_qbvh_walks_against_the_reference_binary(scene):
+    si = scenes.random_tris(20000, seed=13) if scene == "soup20k" else scenes.courtyard(16, 32, 64, seed=7)
+    rays, ld = _rays(si, 1 << 15, 17)
+    ref = ol.RefScene(si, api.ACCEL_BVH4)                    # the reference's own builder and walk
+    r_hits = ref.intersect(rays)
+    r_t, r_occ = ref.shadow(rays, ld)
+    for sah in (False, True):                                # the reference-split tree and the library's SAH tree
+        built = api.BuiltScene(si, api.ACCEL_BVH4, sah=sah)
+        sc = api.Scene(built, 0)
+        g = sc.intersect(rays)
+        g_t, g_occ = sc.shadow(rays, ld)
+        sc.close()
+        assert (r_hits["obj"] >= 0).sum() > 1000
+        # closest hit: a property of the scene -- identical whatever the tree, except which of two exactly-equal-t objects is kept
+        same = (g["obj"] == r_hits["obj"])
+        tie = ~same & (g["t"].view(np.uint32) == r_hits["t"].view(np.uint32)) & (g["obj"] >= 0) & (r_hits["obj"] >= 0)
+        assert np.all(same | tie), int((~(same | tie)).sum())
+        assert tie.sum() <= 8, int(tie.sum())
+        assert ol.same_bits(g["t"], r_hits["t"])
+        assert ol.same_bits(g["beta"][same], r_hits["beta"][same]) and ol.same_bits(g["gamma"][same], r_hits["gamma"][same])
+        # any hit: whether a ray is occluded is a property of the scene; the t of the first hit found is a property of the tree
+        assert np.array_equal(g_occ, r_occ)
+        if not sah:
+            assert ol.same_bits(g_t, r_t)
+
+
+def test_mixed_shapes_against_the_reference_binary():
+    """every object type of shapes/shapes.cpp:4-93 under the QBVH and as non-grid objects, reference control flow (AUTO -> EXACT)"""
+    si = scenes.analytic_scene()
+    rays, ld = _rays_box(8192)
+    ref = ol.RefScene(si, api.ACCEL_BVH4)
+    r_hits = ref.intersect(rays)
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    sc = api.Scene(built, 0)
+    g = sc.intersect(rays)
+    sc.close()
+    assert (r_hits["obj"] >= 0).sum() > 1000
+    differ = g["obj"] != r_hits["obj"]
+    assert differ.sum() <= 8, int(differ.sum())                # class T4: device libm at the phi / theta window seams
+    ok = ~differ
+    a, b = g["t"][ok].astype(np.float64), r_hits["t"][ok].astype(np.float64)
+    assert np.all((np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(b))) | (a == b))
+
+
+def _rays_box(n):
+    r = scenes.random_rays(n, np.array([-6, -2, -6], np.float32), np.array([6, 4, 6], np.float32), seed=29)
+    return r, None
