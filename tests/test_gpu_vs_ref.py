@@ -44,10 +44,17 @@ def test_qbvh_walks_against_the_reference_binary(scene):
         assert tie.sum() <= 8, int(tie.sum())
         assert ol.same_bits(g["t"], r_hits["t"])
         assert ol.same_bits(g["beta"][same], r_hits["beta"][same]) and ol.same_bits(g["gamma"][same], r_hits["gamma"][same])
-        # any hit: whether a ray is occluded is a property of the scene; the t of the first hit found is a property of the tree
-        assert np.array_equal(g_occ, r_occ)
+        # any hit: the t reported is that of the first hit found below light_dist, a property of the tree's visiting order; whether
+        # the ray is occluded is a property of the scene EXCEPT in class T5: a first-found hit inside
+        # [light_dist - K_EPSILON, light_dist) ends the walk and reads "not occluded" even if a nearer occluder comes later in the order
         if not sah:
-            assert ol.same_bits(g_t, r_t)
+            assert ol.same_bits(g_t, r_t) and np.array_equal(g_occ, r_occ)
+        else:
+            d = g_occ != r_occ
+            ldd = ld[d]
+            t5 = lambda t: (t < ldd) & ~(t < ldd - api.K_EPSILON)
+            assert np.all(t5(g_t[d]) | t5(r_t[d])), (g_t[d], r_t[d], ld[d])
+            assert d.sum() <= 4, int(d.sum())
 
 
 def test_mixed_shapes_against_the_reference_binary():
