@@ -159,6 +159,7 @@ EXPORTS = [
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
     "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning", "crt_scene_set_node_compression",
     "crt_host_grid_distance_field", "crt_host_qbvh_node_order", "crt_host_bvh2_wide_records",
+    "crt_scene_set_wide_nodes", "crt_host_qbvh_wide8_records",
     "crt_host_alloc", "crt_host_free",
     "crt_camera_init", "crt_camera_look_at", "crt_camera_set_focal_dist", "crt_film_dimension", "crt_primary_rays_dev",
     "crt_intersect_batch", "crt_shadow_batch", "crt_intersect_batch_dev", "crt_shadow_batch_dev", "crt_intersect_batch_dev_noalloc", "crt_intersect_batch_dev_slice", "crt_shadow_batch_dev_slice", "crt_scene_reserve_rays", "crt_intersect_batch_dev_counted", "crt_shadow_batch_dev_counted", "crt_fill_shade_rec",
@@ -207,6 +208,8 @@ def lib():
     L.crt_host_grid_distance_field.argtypes = [C.POINTER(CrtSceneDesc), vp]
     L.crt_host_qbvh_node_order.argtypes = [C.POINTER(CrtSceneDesc), C.c_int, vp, C.POINTER(C.c_int32)]
     L.crt_host_bvh2_wide_records.argtypes = [C.POINTER(CrtSceneDesc), vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.crt_scene_set_wide_nodes.argtypes = [vp, C.c_int]
+    L.crt_host_qbvh_wide8_records.argtypes = [C.POINTER(CrtSceneDesc), vp, C.POINTER(C.c_int32)]
     f3 = C.POINTER(C.c_float)
     L.crt_camera_init.argtypes = [C.POINTER(CrtCamera), C.c_int, C.c_float, C.c_float]
     L.crt_camera_look_at.argtypes = [C.POINTER(CrtCamera), f3, f3, f3]
@@ -755,6 +758,10 @@ class Scene:
 
     def set_ray_binning(self, on=True):
         _check(lib().crt_scene_set_ray_binning(self._h, 1 if on else 0), "crt_scene_set_ray_binning")
+
+    def set_wide_nodes(self, on=True):
+        """Closest-hit launches walk the 8-wide copy of the QBVH (default) or the 4-wide copies only; same hit records."""
+        _check(lib().crt_scene_set_wide_nodes(self._h, 1 if on else 0), "crt_scene_set_wide_nodes")
 
     def set_node_compression(self, on=True):
         _check(lib().crt_scene_set_node_compression(self._h, 1 if on else 0), "crt_scene_set_node_compression")

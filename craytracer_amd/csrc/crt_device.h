@@ -35,6 +35,7 @@
 struct DevScene {
     const float4* nodes4;
     const uint4* cnodes4;        /* 64-byte conservative copy of nodes4 (4 x uint4 per node), or a dummy */
+    const uint4* wnodes8;        /* the tree once more, up to eight conservative boxes per 128-byte record (crt_wide8_host.h), or a dummy */
     const float4* objs;          /* CRT_OBJ_STRIDE float4 per object */
     const crt_shape* shapes;
     const float4* nodes2;

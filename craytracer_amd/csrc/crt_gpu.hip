@@ -7,6 +7,8 @@
  * a batch of hit records back.
  */
 #include "crt_kernels.h"
+#include "crt_wide8.h"
+#include "crt_wide8_host.h"
 #include "crt_binning.h"
 #include "crt_camera.h"
 
@@ -52,6 +54,7 @@ struct Scratch {
     unsigned* perm; size_t perm_cap;                            /* ray order, one word per ray */
     unsigned short* cells;                                      /* binning cell of every ray (written by the histogram pass, read by the
                                                                    scatter pass instead of the 24-byte ray records), or null */
+    unsigned* fb_list;                                          /* perm_cap words: rays the 8-wide walk leaves to the 4-wide one (crt_wide8.h), or null */
 };
 /* A scene owns CRT_SLOTS sets of launch scratch, used in turn: launch k waits (on the device) only for launch k - CRT_SLOTS, the
  * last one that used ITS set, so two launches enqueued on two streams overlap -- the drain tail of one (its longest rays walking
@@ -80,12 +83,15 @@ struct crt_scene {
     bool count;
     bool compress;            /* walk the 64-byte conservative copy of the QBVH nodes where that is allowed (see crt_scene_set_node_compression) */
     bool cnodes_valid;        /* the copy exists (every node box was finite) */
+    bool wide8_valid;         /* the 8-wide copy exists (crt_wide8_host.h) */
+    bool wide8;               /* ... and closest-hit launches walk it (crt_scene_set_wide_nodes) */
     unsigned split_max_rays;  /* closest-hit batches up to this many rays take the tail-splitting walk */
+    unsigned wide8_min_rays;  /* closest-hit batches of more rays than this take the 8-wide walk (CRT_WIDE8_MIN) */
     bool bvh2_ordered;        /* binary BVH: left-first depth-first order meets the leaves in increasing object index, so the pruned
                                  walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_cnodes4; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
+    void* d_nodes4; void* d_cnodes4; void* d_wnodes8; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
     unsigned long long* d_counters;
     Scratch own[CRT_SLOTS];   /* allocated by crt_scene_create (perm / cells may grow); launch k uses own[k % CRT_SLOTS] */
     unsigned long long slot_last[CRT_SLOTS];   /* launch number (seq) of the last launch through each set, 0 = none yet */
@@ -424,11 +430,11 @@ int upload(void** dst, const std::vector<T>& v)
 void free_scene(crt_scene* s)
 {
     if (!s) return;
-    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist, s->d_cell_objs,
+    void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_wnodes8, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist, s->d_cell_objs,
                      s->d_bnodes2, s->d_bnodes2w, s->d_counters };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < CRT_SLOTS; k++) {
-        void* q[] = { s->own[k].queue_head, s->own[k].ovf_word, s->own[k].ovf_key, s->own[k].bin_hist, s->own[k].bin_cursor, s->own[k].perm, s->own[k].cells };
+        void* q[] = { s->own[k].queue_head, s->own[k].ovf_word, s->own[k].ovf_key, s->own[k].bin_hist, s->own[k].bin_cursor, s->own[k].perm, s->own[k].cells, s->own[k].fb_list };
         for (void* p : q) if (p) (void)hipFree(p);
     }
     for (int k = 0; k < 2; k++) {
@@ -497,6 +503,7 @@ int resolve_noalloc_scratch(int device, Scratch* out)
     out->perm = (unsigned*)(base + CRT_NA_OFF_PERM);
     out->perm_cap = CRT_NA_MAX_RAYS;
     out->cells = 0;                                    /* the scatter pass reads the ray records again */
+    out->fb_list = 0;                                  /* these launches take the 4-wide walk */
     out->ovf_word = (unsigned*)(base + CRT_NA_OFF_OVFW);
     out->ovf_key = (float*)(base + CRT_NA_OFF_OVFK);
     out->ovf_threads = CRT_NA_THREADS;
@@ -524,19 +531,28 @@ const int CRT_MAX_BLOCKS_PER_CU = CRT_MAX_BLOCKS;
 /* How a launch is made.  noalloc: the launch uses the scene's `na` scratch (file-scope array) and never allocates or frees;
  * otherwise the scene's own scratch, whose ray-order buffer grows when a batch is larger than any before
  * (crt_scene_reserve_rays sizes it ahead).  slice_count > 0: only slice `slice` of the batch is walked (see BinSlice). */
+typedef void (*WalkKernel)(DevScene, LaunchArgs);
 struct LaunchOpts {
     bool use_binning; bool noalloc; int max_blocks; unsigned slice, slice_count;
-    LaunchOpts(bool bin = false, bool na = false, int mb = CRT_MAX_BLOCKS_PER_CU) : use_binning(bin), noalloc(na), max_blocks(mb), slice(0), slice_count(0) {}
+    WalkKernel followup;      /* k_bvh8_closest_tri launches: the 4-wide walk that takes the rays the 8-wide one leaves (crt_wide8.h), or null */
+    LaunchOpts(bool bin = false, bool na = false, int mb = CRT_MAX_BLOCKS_PER_CU) : use_binning(bin), noalloc(na), max_blocks(mb), slice(0), slice_count(0), followup(0) {}
 };
+#define CRT_FB_COUNT_WORD 8        /* words of the 256-byte queue-head line (zeroed before every launch): the fallback list's length, */
+#define CRT_FB_HEAD_WORD  16       /* ... and the queue head of the launch that walks it */
 
 int grow_perm(Scratch& sx, size_t n, hipStream_t stream)
 {
     if (n <= sx.perm_cap) return CRT_OK;
     HIPCHK(hipStreamSynchronize(stream));     /* grows only; the previous launch has been waited for */
+    const bool had_fb = sx.fb_list != 0;
     if (sx.perm) { (void)hipFree(sx.perm); sx.perm = 0; sx.perm_cap = 0; }
     if (sx.cells) { (void)hipFree(sx.cells); sx.cells = 0; }
+    if (sx.fb_list) { (void)hipFree(sx.fb_list); sx.fb_list = 0; }
     if (!hip_ok(hipMalloc((void**)&sx.perm, n * sizeof(unsigned)), "hipMalloc")) return CRT_E_NOMEM;
     if (!hip_ok(hipMalloc((void**)&sx.cells, n * sizeof(unsigned short)), "hipMalloc")) { (void)hipFree(sx.perm); sx.perm = 0; return CRT_E_NOMEM; }
+    if (had_fb && !hip_ok(hipMalloc((void**)&sx.fb_list, n * sizeof(unsigned)), "hipMalloc")) {
+        (void)hipFree(sx.perm); sx.perm = 0; (void)hipFree(sx.cells); sx.cells = 0; return CRT_E_NOMEM;
+    }
     sx.perm_cap = n;
     return CRT_OK;
 }
@@ -582,6 +598,14 @@ int launch_locked(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, con
     if (noalloc) HIPCHK(hipMemsetAsync(sx.queue_head, 0, CRT_NA_OFF_CURS, stream));
     else HIPCHK(hipMemsetAsync(sx.queue_head, 0, 256, stream));
     la.perm = 0;
+    WalkKernel followup = o.followup;
+    if (followup && (noalloc || !sx.fb_list)) return CRT_E_INVALID;      /* dispatch_closest does not ask for it then */
+    if (followup && la.n > sx.perm_cap) {                                 /* the fallback list is sized with the ray order */
+        const int rc = grow_perm(sx, la.n, stream);
+        if (rc != CRT_OK) return rc;
+    }
+    la.fb_count = sx.queue_head + CRT_FB_COUNT_WORD;
+    la.fb_list = sx.fb_list;
     if (bin) {
         if (la.n > sx.perm_cap) {
             if (noalloc) return CRT_E_TOOBIG;
@@ -603,6 +627,17 @@ int launch_locked(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, con
     HIPCHK(hipEventRecord(lt.ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CRT_BLOCK), 0, stream, s->dev, la);
     HIPCHK(hipGetLastError());
+    if (followup) {
+        /* the rays the 8-wide walk put on its list (exact-t ties, rays with NaN-capable slab arithmetic, stack overflows: a
+         * handful per 2^24), through the 4-wide walk in the reference's order: a counted launch whose ray order is the list */
+        LaunchArgs fa = la;
+        fa.perm = sx.fb_list; fa.n_dev = la.fb_count; fa.q_range = 0; fa.q_first = 0;
+        fa.queue_head = sx.queue_head + CRT_FB_HEAD_WORD;
+        unsigned fblocks = (unsigned)s->num_cus * 2u;
+        if (fblocks > blocks) fblocks = blocks;
+        hipLaunchKernelGGL(followup, dim3(fblocks), dim3(CRT_BLOCK), 0, stream, s->dev, fa);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(lt.ev_stop, stream));
     if (noalloc) { HIPCHK(hipEventRecord(g_na_ev[s->device], stream)); g_na_ev_recorded[s->device] = true; }
     lt.binned = bin;
@@ -635,6 +670,11 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, LaunchO
                               * LDS stack), and not when objects wait outside the tree: a split ray is settled without the non-grid
                               * loop of intersect.h:403-411. */
                              const unsigned share = o.slice_count > 0 ? la.n / o.slice_count : la.n;
+                             /* the 8-wide copy of the tree (crt_wide8.h), with the 4-wide walk behind it for the rays it leaves */
+                             if (!na && s->wide8 && s->wide8_valid && share > s->wide8_min_rays) {
+                                 o.followup = k_bvh4_closest_tri<COUNT>;
+                                 return launch(s, k_bvh8_closest_tri<COUNT>, la, st, o);
+                             }
                              if (!na && s->dev.nng == 0 && share <= s->split_max_rays) return launch(s, k_bvh4_closest_tri<COUNT, true>, la, st, o);
                              return launch(s, k_bvh4_closest_tri<COUNT>, la, st, o);
                          }
@@ -869,6 +909,17 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             if (!cn_ok) cn4.clear();
         }
         s->cnodes_valid = cn_ok;
+        std::vector<uint32_t> w8;
+        {
+            /* measured slower than the 4-wide walk ("8-wide nodes"), so the copy is made only on request */
+            const char* e = getenv("CRT_WIDE8");
+            const char* ew = getenv("CRT_WIDE8_WIDTH");
+            s->wide8_valid = cn_ok && accel_tri && n - nng > 0 && e && atoi(e) != 0 && wide8::collapse(desc, w8, ew ? atoi(ew) : 8);
+            if (!s->wide8_valid) w8.clear();
+            s->wide8 = s->wide8_valid;
+            e = getenv("CRT_WIDE8_MIN");
+            s->wide8_min_rays = e ? (unsigned)strtoul(e, 0, 10) : 0u;
+        }
         { const char* e = getenv("CRT_TAIL_SPLIT_MAX"); s->split_max_rays = e ? (unsigned)strtoul(e, 0, 10) : CRT_SPLIT_MAX_RAYS_DEFAULT; }
         s->compress = true;
 
@@ -939,7 +990,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             const char* e = getenv("CRT_GRID_SKIP");                      /* A/B knob: 0 = no cell is skipped, as the reference walks */
             if (e && atoi(e) == 0) for (size_t c = 0; c < cd.size(); c++) if (cd[c] > 1) cd[c] = 1;
         }
-        if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK ||
+        if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK || (rc = upload(&s->d_wnodes8, w8)) != CRT_OK ||
             (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_bnodes2w, b2w)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK ||
             (rc = upload(&s->d_cell_dist, cd)) != CRT_OK || (!co.empty() && (rc = upload(&s->d_cell_objs, co)) != CRT_OK)) {
@@ -968,10 +1019,12 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
              * nor synchronises; a larger batch still grows it (launch(); crt_scene_reserve_rays does it ahead of time) */
             sx.perm_cap = CRT_PERM_PRESIZE;
             if (!hip_ok(hipMalloc((void**)&sx.perm, sx.perm_cap * sizeof(unsigned)), "hipMalloc") ||
-                !hip_ok(hipMalloc((void**)&sx.cells, sx.perm_cap * sizeof(unsigned short)), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
+                !hip_ok(hipMalloc((void**)&sx.cells, sx.perm_cap * sizeof(unsigned short)), "hipMalloc") ||
+                (s->wide8_valid && !hip_ok(hipMalloc((void**)&sx.fb_list, sx.perm_cap * sizeof(unsigned)), "hipMalloc"))) { free_scene(s); return CRT_E_NOMEM; }
         }
         if (!hip_ok(hipMemset(sx.bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     }
+    for (int k = 0; k < CRT_SLOTS; k++) if (!s->own[k].fb_list) s->wide8_valid = false;       /* no list, no 8-wide walk */
     if (!hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
     if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     for (int k = 0; k < CRT_TIMING_RING; k++) {
@@ -988,6 +1041,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     DevScene& dv = s->dev;
     dv.nodes4 = (const float4*)s->d_nodes4;
     dv.cnodes4 = (const uint4*)s->d_cnodes4;
+    dv.wnodes8 = (const uint4*)s->d_wnodes8;
     dv.objs = (const float4*)s->d_objs;
     dv.shapes = (const crt_shape*)s->d_shapes;
     dv.nodes2 = (const float4*)s->d_nodes2;
@@ -1085,6 +1139,28 @@ int crt_scene_set_node_compression(crt_scene* s, int on)
     if (!s) return CRT_E_INVALID;
     std::lock_guard<std::mutex> lock(s->mu);
     s->compress = on != 0;
+    return CRT_OK;
+}
+int crt_scene_set_wide_nodes(crt_scene* s, int on)
+{
+    if (!s) return CRT_E_INVALID;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (on && !s->wide8_valid) return CRT_E_UNSUPPORTED;          /* the scene was created without the copy */
+    s->wide8 = on != 0;
+    return CRT_OK;
+}
+int crt_host_qbvh_wide8_records(const crt_scene_desc* desc, uint32_t* records, int32_t* num_records)
+{
+    if (!desc || !num_records || desc->accel != CRT_ACCEL_BVH4) return CRT_E_INVALID;
+    int d4 = 0, d2 = 0;
+    try {
+        const int rc = validate_desc(desc, &d4, &d2);
+        if (rc != CRT_OK) return rc;
+        std::vector<uint32_t> w8;
+        const bool ok = desc->num_nodes4 > 0 && wide8::collapse(desc, w8);
+        *num_records = ok ? (int32_t)(w8.size() / CRT_W8_WORDS) : 0;
+        if (ok && records) memcpy(records, w8.data(), w8.size() * sizeof(uint32_t));
+    } catch (const std::bad_alloc&) { return CRT_E_NOMEM; }
     return CRT_OK;
 }
 int crt_scene_set_ray_binning(crt_scene* s, int on)

@@ -48,6 +48,8 @@ struct LaunchArgs {
     const unsigned* q_range;      /* slice launches (crt_intersect_batch_dev_slice): {first, end} queue slot of this launch's share of the
                                      binned batch, written by k_bin_scan; or null: the whole queue */
     unsigned q_first;             /* first queue slot of the launch (0 unless q_range, or a slice by ray index) */
+    unsigned* fb_count;           /* k_bvh8_closest_tri: rays it leaves to the 4-wide walk of the same launch (crt_wide8.h): how many, */
+    unsigned* fb_list;            /* ... and their indices */
 };
 /* first statement of every walk kernel: the launch's ray count and the part of the queue it walks, [q_first, n) */
 CRT_DEV void resolve_count(LaunchArgs& la)

@@ -227,6 +227,18 @@ int  crt_scene_set_ray_binning(crt_scene* s, int on);
  * nodes in the same order and returns the same hit records bit for bit. */
 int  crt_scene_set_node_compression(crt_scene* s, int on);
 
+/* 8-wide node copy (experiment switch, off by default: measured 0.83 x the 4-wide walk, DESIGN.md "8-wide nodes").  No
+ * counterpart in the reference.  When the environment variable CRT_WIDE8 is 1 at crt_scene_create, a triangle-only QBVH scene
+ * keeps a third copy of the tree with up to eight conservative boxes per 128-byte record, cut out of the same binary hierarchy
+ * so as to minimise the expected number of node visits, and closest-hit launches (not the no-allocation entry point) walk that
+ * copy near to far: 37 % fewer dependent node fetches per ray.  What BVH4IntersectTest returns beyond the nearest t -- WHICH of
+ * several objects at exactly that t -- depends on its visiting order, so every ray for which that could matter (two objects
+ * compare equal at the nearest t; a ray whose slab arithmetic can produce NaN; a ray whose pending children overflow the lane's
+ * stack) is put on a list and walked again, inside the same call, by the 4-wide walk in the reference's order.  Hit records are
+ * therefore the same bit for bit; the node / primitive counters count the walk that ran.  on = 0: walk the 4-wide copies;
+ * on = 1 without the copy: CRT_E_UNSUPPORTED. */
+int  crt_scene_set_wide_nodes(crt_scene* s, int on);
+
 /* Three host-side steps of crt_scene_create, exported so that they can be checked without a GPU (tests/test_host_layout.py).
  * No counterpart in the reference; neither touches a device.
  *  - crt_host_grid_distance_field: for a CRT_ACCEL_GRID description, out[cell] = chessboard (Chebyshev) distance from the cell
@@ -244,6 +256,12 @@ int  crt_host_qbvh_node_order(const crt_scene_desc* desc, int policy, int32_t* o
  *    maxx[4] maxy[4] maxz[4], four child words (record index, 0x80000000 | object index, 0xFFFFFFFF = unused slot), four unused.
  *    `records` may be null (count only) and otherwise holds at most num_nodes2 records; *num_records = 0 when the tree does
  *    not qualify. */
+/*  - crt_host_qbvh_wide8_records: for a CRT_ACCEL_BVH4 description, the 8-wide copy crt_scene_create makes (see
+ *    crt_scene_set_wide_nodes): 32 words per record -- frame origin (3 floats), three biased power-of-two exponents packed in one
+ *    word, 48 plane bytes lo_x[8] lo_y[8] lo_z[8] hi_x[8] hi_y[8] hi_z[8] (plane = origin + byte * 2^(e - 127), rounded outward),
+ *    eight child words (record index | 0x80000000 | count << 28 | first object), eight unused.  `records` may be null (count
+ *    only) and otherwise holds at most num_nodes4 records; *num_records = 0 when the tree does not qualify. */
+int  crt_host_qbvh_wide8_records(const crt_scene_desc* desc, uint32_t* records, int32_t* num_records);
 int  crt_host_bvh2_wide_records(const crt_scene_desc* desc, float* records, int32_t* num_records, int32_t* leaves_in_index_order);
 
 /* n x intersectTest (intersect.h:365-440).  Host buffers: the batch is cut into chunks whose

@@ -161,6 +161,7 @@ def test_counters_match_the_oracles_walk(scene, mode, monkeypatch):
     # the plain walk: in the tail-splitting walk (small batches) which lane takes which subtree depends on timing, so its
     # counts vary from run to run by a fraction of a per cent, in either direction
     monkeypatch.setenv("CRT_TAIL_SPLIT_MAX", "0")
+    monkeypatch.setenv("CRT_WIDE8", "1")
     si = scenes.courtyard(4, 16, 32, seed=2) if scene == "blobs" else scenes.analytic_scene()
     if scene == "blobs":
         rays, ld = rayset(si, 4096, 9)
@@ -180,12 +181,23 @@ def test_counters_match_the_oracles_walk(scene, mode, monkeypatch):
         # the 64-byte conservative node copy: boxes that contain the reference's, so a superset of the oracle's walk (a
         # few per cent more boxes and triangles), in the same order, and the same hit records bit for bit
         sc.set_node_compression(True)
+        sc.set_wide_nodes(False)
         sc.reset_counters()
         g_comp = sc.intersect(rays)
         cc = sc.counters()
         assert ol.same_bits(g_comp, g_full)
         assert oc["nodes_visited"] <= cc["nodes_visited"] <= 1.1 * oc["nodes_visited"]
         assert oc["prims_tested"] <= cc["prims_tested"] <= 1.1 * oc["prims_tested"]
+        # the 8-wide copy (on request): each node has absorbed some of its inner children, so far fewer visits; rays whose
+        # answer could hang on the visiting order are walked again by the 4-wide walk -- the same hit records bit for bit
+        sc.set_wide_nodes(True)
+        sc.reset_counters()
+        g_wide = sc.intersect(rays)
+        cw = sc.counters()
+        assert ol.same_bits(g_wide, g_full)
+        assert cw["rays_closest"] == len(rays)
+        assert 0.3 * oc["nodes_visited"] <= cw["nodes_visited"] <= 0.8 * oc["nodes_visited"]
+        assert 0.8 * oc["prims_tested"] <= cw["prims_tested"] <= 1.3 * oc["prims_tested"]
     assert c["rays_closest"] == len(rays)
     if scene == "blobs":
         assert c["nodes_visited"] == oc["nodes_visited"] and c["prims_tested"] == oc["prims_tested"]

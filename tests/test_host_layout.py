@@ -137,3 +137,69 @@ def test_binary_bvh_of_one_object_is_not_collapsed():
     assert api.lib().crt_host_bvh2_wide_records(C.byref(built.desc), None, C.byref(n), C.byref(ordered)) == 0
     assert n.value == 0 and ordered.value == 1                            # the root is a leaf: the two-box walk handles it
     built.close()
+
+
+@pytest.mark.parametrize("sah", [False, True])
+@pytest.mark.parametrize("scene", ["blobs", "soup", "one", "five"])
+def test_qbvh_eight_wide_records(scene, sah):
+    """crt_host_qbvh_wide8_records: the copy of the QBVH with up to eight children per record.  Every object sits in exactly one
+    leaf child, leaves are the 4-wide tree's leaves, every child's box lies inside its quantised box, children come after their
+    parent, and every record is reachable from record 0 exactly once."""
+    si = {"blobs": lambda: scenes.courtyard(3, 16, 32, seed=4), "soup": lambda: scenes.random_tris(3000, seed=5),
+          "one": lambda: scenes.random_tris(1, seed=6), "five": lambda: scenes.random_tris(5, seed=7)}[scene]()
+    built = api.BuiltScene(si, api.ACCEL_BVH4, sah=sah)
+    d = built.desc
+    n = C.c_int32(-1)
+    assert api.lib().crt_host_qbvh_wide8_records(C.byref(d), None, C.byref(n)) == 0
+    assert 1 <= n.value <= d.num_nodes4
+    rec = np.zeros((d.num_nodes4, 32), np.uint32)
+    assert api.lib().crt_host_qbvh_wide8_records(C.byref(d), rec.ctypes.data_as(C.c_void_p), C.byref(n)) == 0
+    rec = rec[:n.value]
+    nodes = built.nodes4
+    # the 4-wide tree's leaves: (first, count) -> box
+    leaf_box = {}
+    for nd in nodes:
+        for c in range(4):
+            if nd["type"][c] > 0:
+                leaf_box[(int(nd["child"][c]), int(nd["type"][c]))] = (nd["bbox"][[c, 4 + c, 8 + c]], nd["bbox"][[12 + c, 16 + c, 20 + c]])
+    seen_obj = np.zeros(d.num_obj, np.int32)
+    seen_rec = np.zeros(len(rec), np.int32)
+    seen_rec[0] = 1
+    leaves = 0
+    # box of each record = union of its children's quantised boxes; a child record's children must lie inside the box the parent holds for it
+    held = {0: (np.full(3, -np.inf), np.full(3, np.inf))}
+    for r, w in enumerate(rec):
+        origin = w[0:3].view(np.float32).astype(np.float64)
+        e = np.array([w[3] & 0xFF, (w[3] >> 8) & 0xFF, (w[3] >> 16) & 0xFF], np.int64)
+        assert np.all(e >= 1) and np.all(e <= 254)
+        scale = np.ldexp(1.0, (e - 127).astype(np.int32))
+        planes = w[4:16].view(np.uint8).reshape(6, 8).astype(np.float64)
+        lo_p, hi_p = held[r]
+        live = 0
+        for s in range(8):
+            word = int(w[16 + s])
+            qlo = origin + planes[0:3, s] * scale
+            qhi = origin + planes[3:6, s] * scale
+            if word & 0x80000000:
+                cnt, first = (word >> 28) & 7, word & 0x0FFFFFFF
+                if cnt == 0:
+                    assert np.all(planes[0:3, s] == 255) and np.all(planes[3:6, s] == 0)      # unused slot: an inverted box
+                    continue
+                live += 1
+                leaves += 1
+                assert (first, cnt) in leaf_box
+                blo, bhi = leaf_box[(first, cnt)]
+                assert np.all(qlo <= blo) and np.all(qhi >= bhi)
+                seen_obj[first:first + cnt] += 1
+            else:
+                live += 1
+                assert r < word < len(rec)
+                seen_rec[word] += 1
+                held[word] = (qlo, qhi)
+            assert np.all(qlo >= lo_p - 1e-3 * np.abs(lo_p) - 1e-6) or r == 0        # (quantisation of the parent is coarser: only a sanity bound)
+        assert live >= 1 or d.num_obj == 0
+    assert np.all(seen_rec == 1)
+    assert np.all(seen_obj[d.num_non_grid_obj:] == 1)
+    assert leaves == len(leaf_box)
+    if scene == "blobs" and sah:
+        assert len(rec) < 0.62 * d.num_nodes4                      # about half as many records as 4-wide nodes
