@@ -168,6 +168,7 @@ EXPORTS = [
     "crt_scene_device", "crt_scene_num_objects", "crt_renderer_create", "crt_renderer_destroy", "crt_renderer_render", "crt_renderer_read",
     "crt_renderer_get_stats", "crt_renderer_read_dev", "crt_renderer_reset",
     "crt_bake_mesh", "crt_obj_load", "crt_obj_free", "crt_mesh_normals_tangents", "crt_image_state_save", "crt_image_state_load", "crt_image_state_free", "crt_image_from_color_buffer", "crt_ppm_write",
+    "crt_texture_load_ppm", "crt_texture_free",
 ]
 
 _lib = None
@@ -256,6 +257,9 @@ def lib():
     L.crt_image_state_free.restype = None
     L.crt_image_from_color_buffer.argtypes = [vp, vp, C.c_int, C.c_int]
     L.crt_ppm_write.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    L.crt_texture_load_ppm.argtypes = [C.c_char_p, C.POINTER(CrtTexture)]
+    L.crt_texture_free.argtypes = [C.POINTER(CrtTexture)]
+    L.crt_texture_free.restype = None
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_strerror.restype = C.c_char_p
     L.crt_last_hip_error.argtypes = []
@@ -451,7 +455,10 @@ class CrtSceneFileView(C.Structure):
                 ("mesh_shading", CrtMeshShading), ("has_film", C.c_int32), ("window_width", C.c_int32), ("window_height", C.c_int32),
                 ("image_width", C.c_int32), ("image_height", C.c_int32), ("fov", C.c_float), ("has_camera", C.c_int32),
                 ("camera_pos", C.c_float * 3), ("look_point", C.c_float * 3), ("has_env_light", C.c_int32),
-                ("env_color", C.c_float * 3), ("env_intensity", C.c_float), ("num_skipped", C.c_int32), ("num_unsupported", C.c_int32)]
+                ("env_color", C.c_float * 3), ("env_intensity", C.c_float), ("num_skipped", C.c_int32), ("num_unsupported", C.c_int32),
+                ("num_textures", C.c_int32), ("texture_names", C.POINTER(C.c_char_p)), ("textures", C.POINTER(CrtTexture)),
+                ("material_diffuse_tex", C.POINTER(C.c_int32)), ("material_normal_tex", C.POINTER(C.c_int32)),
+                ("env_type", C.c_int32), ("env_map_tex", C.c_int32), ("env_transform", C.c_float * 9), ("num_external", C.c_int32)]
 
 
 class SceneFile:
@@ -492,20 +499,48 @@ class SceneFile:
             self.film = (v.window_width, v.window_height, v.image_width, v.image_height, float(v.fov)) if v.has_film else None
             self.camera = (tuple(v.camera_pos), tuple(v.look_point)) if v.has_camera else None
             self.env_light = (tuple(v.env_color), float(v.env_intensity)) if v.has_env_light else None
-            self.num_skipped, self.num_unsupported = v.num_skipped, v.num_unsupported
+            self.num_skipped, self.num_unsupported, self.num_external = v.num_skipped, v.num_unsupported, v.num_external
+            # textures: names in order of first mention; texels where the loader could read them (PPM), else None
+            self.texture_names = [v.texture_names[i].decode() for i in range(v.num_textures)]
+            self.textures = []
+            for i in range(v.num_textures):
+                t = v.textures[i]
+                if t.data:
+                    dt = np.float32 if t.is_float else np.uint8
+                    self.textures.append(arr(t.data, t.width * t.height * t.comp, dt).reshape(t.height, t.width, t.comp))
+                else:
+                    self.textures.append(None)
+            self.material_diffuse_tex = arr(C.cast(v.material_diffuse_tex, C.c_void_p).value, nm, np.int32)
+            self.material_normal_tex = arr(C.cast(v.material_normal_tex, C.c_void_p).value, nm, np.int32)
+            self.env_type, self.env_map_tex = v.env_type, v.env_map_tex
+            self.env_transform = np.array(list(v.env_transform), np.float32).reshape(3, 3)
         finally:
             L.crt_scene_file_free(h)
 
-    def render_desc(self, max_depth, built=None, seed=0, samples_in_flight=0, world_radius=None):
+    def render_desc(self, max_depth, built=None, seed=0, samples_in_flight=0, world_radius=None, texels=None, rows=None):
         """RenderDesc for this scene.  The env light's world radius comes from the built accelerator as in
-        preprocessLights (crt_env_world_radius) unless given."""
+        preprocessLights (crt_env_world_radius) unless given.  texels: {file name: [h, w, 3] array} for textures the loader
+        named but did not read (the .exr environment map: float32)."""
         env = None
         if self.env_light is not None:
             if world_radius is None:
                 world_radius = env_world_radius(built)
             env = (self.env_light[0], self.env_light[1], world_radius)
+        textures, diffuse, env_map, env_xf = None, None, None, None
+        if self.texture_names:
+            textures = []
+            for name, t in zip(self.texture_names, self.textures):
+                if texels and name in texels:
+                    t = texels[name]
+                if t is None:
+                    raise ValueError("texture %r: the loader could not read it and no texels were given" % name)
+                textures.append(t)
+            diffuse = self.material_diffuse_tex
+            if self.env_type == 1 and self.env_map_tex >= 0:
+                env_map, env_xf = self.env_map_tex, self.env_transform
         return RenderDesc(self.scene_input, self.obj_material, self.materials, max_depth, seed=seed, env=env,
-                          samples_in_flight=samples_in_flight, mesh_shading=self.mesh_shading)
+                          samples_in_flight=samples_in_flight, mesh_shading=self.mesh_shading, textures=textures,
+                          material_diffuse_tex=diffuse, env_map=env_map, env_transform=env_xf, rows=rows)
 
 
 def env_world_radius(built, L=None):
@@ -676,6 +711,16 @@ def image_from_color_buffer(color_buffer, num_samples):
     _check(lib().crt_image_from_color_buffer(img.ctypes.data, cb.ctypes.data, cb.size // 3, int(num_samples)),
            "crt_image_from_color_buffer")
     return img
+
+
+def texture_load_ppm(path):
+    """crt_texture_load_ppm (PPM_read, imagefile.h:59-83): a binary P6 file as a [h, w, 3] uint8 array."""
+    t = CrtTexture()
+    _check(lib().crt_texture_load_ppm(os.fsencode(path), C.byref(t)), "crt_texture_load_ppm")
+    try:
+        return np.frombuffer(C.string_at(t.data, t.width * t.height * t.comp), np.uint8).reshape(t.height, t.width, t.comp).copy()
+    finally:
+        lib().crt_texture_free(C.byref(t))
 
 
 def ppm_write(path, image):

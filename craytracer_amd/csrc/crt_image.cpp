@@ -86,4 +86,36 @@ int crt_ppm_write(const char* file_name, const unsigned char* image, int width, 
     return (wrote == size && !bad) ? CRT_OK : CRT_E_INVALID;
 }
 
+/* PPM_read (imagefile.h:59-83): "P6", width height, maxval, then width*height*3 bytes.  The reference reads the header with
+ * fscanf("%d\n"), whose trailing white-space directive also swallows pixel bytes that happen to be 0x09-0x0d / 0x20 at the start
+ * of the data (the quirk crt_image_state_load documents for readImageState); here exactly one white-space byte follows maxval,
+ * as the format says and as PPM_write / crt_ppm_write leave it.  A short file is an error (the reference prints and goes on). */
+int crt_texture_load_ppm(const char* file_name, crt_texture* out)
+{
+    if (!file_name || !out) return CRT_E_INVALID;
+    memset(out, 0, sizeof *out);
+    FILE* fp = fopen(file_name, "rb");
+    if (!fp) return CRT_E_INVALID;
+    char magic[16];
+    int w = 0, h = 0, maxval = 0;
+    if (fscanf(fp, "%15s", magic) != 1 || strcmp(magic, "P6") != 0 || fscanf(fp, "%d %d", &w, &h) != 2 || fscanf(fp, "%d", &maxval) != 1 ||
+        w < 1 || h < 1 || w > 65536 || h > 65536 || maxval != 255) { fclose(fp); return CRT_E_INVALID; }
+    const int c = fgetc(fp);                                   /* the single white-space byte after maxval */
+    if (!(c == '\n' || c == ' ' || c == '\t' || c == '\r')) { fclose(fp); return CRT_E_INVALID; }
+    const size_t size = (size_t)w * (size_t)h * 3;
+    unsigned char* buf = (unsigned char*)malloc(size);
+    if (!buf) { fclose(fp); return CRT_E_NOMEM; }
+    const size_t got = fread(buf, 1, size, fp);
+    fclose(fp);
+    if (got != size) { free(buf); return CRT_E_INVALID; }
+    out->width = w; out->height = h; out->comp = 3; out->is_float = 0; out->data = buf;
+    return CRT_OK;
+}
+void crt_texture_free(crt_texture* t)
+{
+    if (!t) return;
+    free(const_cast<void*>(t->data));
+    t->data = 0;
+}
+
 } // extern "C"

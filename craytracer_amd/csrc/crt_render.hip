@@ -570,10 +570,20 @@ __global__ __launch_bounds__(256) void k_pt_shade(RenderDev rd, unsigned n_max, 
                 /* Matte_getDiffuseColor / Plastic.diffuse (materials.cpp:51-60,:146-149) at the hit's texcoord: interpTexcoord + the
                  * [0, 1] wrap of rayIntersectFlatTriangle / SmoothTriangle (triangle.cpp:191-198,:237-243); create() admits textured
                  * materials on these two kinds only */
-                const size_t tri = (size_t)__float_as_int(so.type == CRT_SMOOTH_TRIANGLE ? so.p[0] : so.p[13]);
                 float uv[2], c[3];
-                sr_interp_uv(uv, hit.beta, hit.gamma, rd.vuv + 6 * tri);
-                sr_wrap_uv(uv);
+                if (so.type == CRT_SPHERE || so.type == CRT_RECTANGLE) {
+                    /* ShadeRec.uv as the object's own intersector writes it (sphere.cpp:14-19: phi / 2 pi and theta / pi of the root
+                     * that was accepted; rect.cpp:28-37: the two edge coordinates), through the code crt_fill_shade_rec runs.  Not
+                     * wrapped: getTexColor mirrors a negative u itself.  Device atan2f / acosf: class T4 (a texel boundary) */
+                    crt_shade_rec sr;
+                    sr.written = 0; sr.uv[0] = sr.uv[1] = 0.0f;
+                    sr_fill_simple(&rd.shapes[__float_as_int(so.p[13])], ray.o, ray.d, hit.t, 1, &sr);
+                    uv[0] = sr.uv[0]; uv[1] = sr.uv[1];
+                } else {
+                    const size_t tri = (size_t)__float_as_int(so.type == CRT_SMOOTH_TRIANGLE ? so.p[0] : so.p[13]);
+                    sr_interp_uv(uv, hit.beta, hit.gamma, rd.vuv + 6 * tri);
+                    sr_wrap_uv(uv);
+                }
                 const crt_texture t = rd.tex[rd.mat_tex[so.mat]];
                 crt_tex_color(c, t.width, t.height, t.comp, t.is_float, t.data, uv);
                 cd = v3p(c);
@@ -900,8 +910,11 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         ShadeObj so; memset(&so, 0, sizeof so);
         so.type = type; so.mat = mi;
         if (any_tex && d->material_diffuse_tex[mi] >= 0 && (mt.type == CRT_MAT_MATTE || mt.type == CRT_MAT_PLASTIC)) {
-            /* a texture needs a texcoord the reference defines: the mesh triangle kinds (triangle.cpp:191-198,:237-243) */
-            if ((type != CRT_FLAT_TRIANGLE && type != CRT_SMOOTH_TRIANGLE) || !ms || !ms->vertex_uv) return CRT_E_UNSUPPORTED;
+            /* a texture needs a texcoord the reference defines: the mesh triangle kinds (triangle.cpp:191-198,:237-243), and the
+             * sphere and the rectangle, whose intersectors write ShadeRec.uv (fillShadeRecSphere, sphere.cpp:14-19; rect.cpp:28-37) */
+            if (type == CRT_FLAT_TRIANGLE || type == CRT_SMOOTH_TRIANGLE) { if (!ms || !ms->vertex_uv) return CRT_E_UNSUPPORTED; }
+            else if (type == CRT_SPHERE || type == CRT_RECTANGLE) any_generic = true;      /* the shape table goes to the device */
+            else return CRT_E_UNSUPPORTED;
         }
         /* EMISSIVE mesh triangles: initMeshLights (buildscene.h:749-833) registers them as MeshLights, which preprocessLights
          * gives no power (no MESHLIGHT case, buildscene.h:879-917) and estimateDirect cannot sample ("Invalid light type",
@@ -927,6 +940,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         } else if (type == CRT_RECTANGLE || type == CRT_SPHERE || type == CRT_DISK) {
             if (ref < 0 || ref >= in->num_shapes || !in->shapes || in->shapes[ref].type != type) return CRT_E_INVALID;
             const float* sp = in->shapes[ref].p;
+            memcpy(so.p + 13, &ref, 4);                           /* index into shapes[]: the uv of a textured sphere / rectangle */
             if (type == CRT_RECTANGLE) {
                 memcpy(so.p, sp + 9, 12);                         /* normal */
                 host_normalize(so.p + 3, sp + 3);                 /* dpdu = normalize(width), rect.cpp:35 */
@@ -1078,8 +1092,10 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
         if (any_tex) {
             ok = ok && dev_alloc(r, &d_mat_tex, (size_t)d->num_materials) == CRT_OK;
             ok = ok && hipMemcpy(d_mat_tex, d->material_diffuse_tex, (size_t)d->num_materials * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
-            ok = ok && dev_alloc(r, &d_vuv, 6 * (size_t)in->num_tris) == CRT_OK;
-            ok = ok && hipMemcpy(d_vuv, ms->vertex_uv, 6 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+            if (ms && ms->vertex_uv && in->num_tris > 0) {
+                ok = ok && dev_alloc(r, &d_vuv, 6 * (size_t)in->num_tris) == CRT_OK;
+                ok = ok && hipMemcpy(d_vuv, ms->vertex_uv, 6 * (size_t)in->num_tris * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+            }
         }
     }
     ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;

@@ -19,9 +19,13 @@
  *     a well-formed file of the current grammar reads exactly as the reference reads it;
  *   - '\t' and '\r' separate tokens too (the reference splits on ' ' and '\n' only);
  *   - `#` starts a comment at the top level anywhere in the file (the reference: only after END_MATERIALS);
- *   - textures (TEXTURE / KD_TEXTURE / NORMAL_MAP, ENV_LIGHT TYPE TEXTURE) are not loaded: the entry keeps white
- *     and view.num_unsupported counts it; material types the current reference rejects (the old REFLECTIVE, PHONG)
- *     are kept as type 0 so that object -> material indices stay stable;
+ *   - textures (TEXTURE / KD_TEXTURE / NORMAL_MAP, ENV_LIGHT TYPE TEXTURE) are bound by file name as the reference binds
+ *     them (Scene_addTexture while parsing, linkMaterialTextures afterwards) and read with crt_texture_load_ppm -- the
+ *     reference's loadTexture is stb_image, which it does not ship; PPM is the format its own imagefile.h reads.  A file
+ *     that cannot be read leaves an entry without texels and view.num_unsupported counts it; the .exr environment map
+ *     (read through OpenEXR in the reference) is named, its texels are the caller's to supply;
+ *   - material types the current reference rejects (the old REFLECTIVE, PHONG) are kept as type 0 so that
+ *     object -> material indices stay stable;
  *   - a mesh file named by two entries is baked once per entry (the reference reloads it and bakes every copy found
  *     by name again, buildscene.h:426-441).
  */
@@ -138,10 +142,31 @@ struct Loaded {
     std::vector<crt_material> materials;
     std::vector<std::string> names;
     std::vector<const char*> name_ptrs;
+    std::vector<std::string> tex_names;
+    std::vector<const char*> tex_name_ptrs;
+    std::vector<crt_texture> textures;
+    std::vector<int32_t> mat_diffuse_tex, mat_normal_tex;
     std::string dir;
     crt_scene_file_view view;
     bool any_mesh;
 };
+
+/* Scene_findTexture, else loadTexture + Scene_addTexture (parseTexture, scenefile.h:92-111): index of the entry of that name.
+ * external: the texels are not ours to read (the .exr environment map). */
+int bind_texture(Loaded& L, const std::string& file, bool external)
+{
+    for (size_t i = 0; i < L.tex_names.size(); i++) if (L.tex_names[i] == file) return (int)i;
+    crt_texture t; memset(&t, 0, sizeof t);
+    if (external) { t.is_float = 1; t.comp = 3; L.view.num_external++; }
+    else {
+        int rc = crt_texture_load_ppm(file.c_str(), &t);
+        if (rc != CRT_OK && !L.dir.empty() && file[0] != '/') rc = crt_texture_load_ppm((L.dir + "/" + file).c_str(), &t);
+        if (rc != CRT_OK) { memset(&t, 0, sizeof t); L.view.num_unsupported++; }
+    }
+    L.tex_names.push_back(file);
+    L.textures.push_back(t);
+    return (int)L.textures.size() - 1;
+}
 
 int find_material(const Loaded& L, const std::string& name)          /* Scene_findMaterial; -1 = NULL */
 {
@@ -194,6 +219,7 @@ void parse_material(Loaded& L, Tokens& tk)
     else { m.type = 0; L.view.num_unsupported++; }
     std::string name;
     float diff_constant = 1.0f; bool legacy_diffuse = false;
+    int diffuse_tex = -1, normal_tex = -1;
     while (tk.next(&t) && t != "END") {
         if (t == "MATERIAL" || t == "END_MATERIALS" || t == "OBJECT") {     /* an entry of the old grammar without END (example_scene.txt) */
             tk.push_back(t);
@@ -202,7 +228,8 @@ void parse_material(Loaded& L, Tokens& tk)
         float v, c3[3];
         if (t == "NAME") tk.next(&name);
         else if (t == "COLOR") { if (color(tk, c3)) memcpy(m.color, c3, 12); }
-        else if (t == "TEXTURE" || t == "KD_TEXTURE" || t == "NORMAL_MAP") { tk.next(&t); L.view.num_unsupported++; }
+        else if (t == "TEXTURE" || t == "KD_TEXTURE") { if (tk.next(&t)) diffuse_tex = bind_texture(L, t, false); }   /* scenefile.h:141-147,:225-233 */
+        else if (t == "NORMAL_MAP") { if (tk.next(&t)) normal_tex = bind_texture(L, t, false); }                       /* :161-171 */
         else if (t == "SIGMA") { if (tk.number(&v)) m.sigma = v; }
         else if (t == "IOR_IN") { if (tk.number(&v)) m.ior_in = v; }
         else if (t == "IOR_OUT") { if (tk.number(&v)) m.ior_out = v; }
@@ -221,8 +248,13 @@ void parse_material(Loaded& L, Tokens& tk)
     }
     if (legacy_diffuse) for (int k = 0; k < 3; k++) m.color[k] *= diff_constant;       /* kd * cd of the old Matte */
     if (m.type != CRT_MAT_TRANSPARENT && m.type != CRT_MAT_GLASS) { m.ior_in = 1.0f; m.ior_out = 1.0f; }
+    /* linkMaterialTextures (buildscene.h:315-342) links MATTE and PLASTIC only */
+    if (m.type != CRT_MAT_MATTE && m.type != CRT_MAT_PLASTIC) diffuse_tex = -1;
+    if (m.type != CRT_MAT_MATTE) normal_tex = -1;
     L.materials.push_back(m);
     L.names.push_back(name);
+    L.mat_diffuse_tex.push_back(diffuse_tex);
+    L.mat_normal_tex.push_back(normal_tex);
 }
 
 /* NormalType, shapes/generic.h:13-18; -1: invalid */
@@ -366,19 +398,31 @@ void parse_object(Loaded& L, Tokens& tk)
         L.view.num_skipped++;
 }
 
-/* ENV_LIGHT TYPE CONSTANT COLOR <c> INTENSITY <v>  (buildscene.h:451-534) */
+/* ENV_LIGHT TYPE CONSTANT COLOR <c> INTENSITY <v> | TYPE TEXTURE COLOR <file> INTENSITY <v>  (buildscene.h:451-534) */
 void parse_env_light(Loaded& L, Tokens& tk)
 {
     std::string t;
     float c3[3] = {1.0f, 1.0f, 1.0f}, intensity = 0.0f;
     tk.next(&t);                                                    /* TYPE */
     tk.next(&t);
+    L.view.env_type = 0; L.view.env_map_tex = -1;
+    memset(L.view.env_transform, 0, sizeof L.view.env_transform);
     if (t == "CONSTANT") {
         tk.next(&t);                                                /* COLOR */
         color(tk, c3);
-    } else {                                                        /* TEXTURE <file>: environment maps are not loaded; white, as for a non-exr file (:484-488) */
-        tk.next(&t); tk.next(&t);
-        L.view.num_unsupported++;
+    } else {                                                        /* TEXTURE: COLOR <file> */
+        tk.next(&t);
+        std::string file;
+        tk.next(&file);
+        const size_t dot = file.find_last_of('.');                  /* "check extension", buildscene.h:470-477 */
+        if (dot != std::string::npos && file.substr(dot + 1) == "exr") {
+            L.view.env_type = 1;                                    /* readRgba1: OpenEXR, float texels, comp 3 (:478-483) */
+            L.view.env_map_tex = bind_texture(L, file, true);
+        }                                                           /* any other extension: CONSTANT and WHITE (:484-488) */
+        const float th = -0.76f;                                    /* mat3_rotate_y(env_light->transform, -0.76), :515, util/mat.h:229-238 */
+        const float sn = sinf(th), cs = cosf(th);                    /* (float)sin(theta) on a float argument: the float overload */
+        const float xf[9] = { cs, 0.0f, sn, 0.0f, 1.0f, 0.0f, -sn, 0.0f, cs };
+        memcpy(L.view.env_transform, xf, sizeof xf);
     }
     tk.next(&t);                                                    /* INTENSITY */
     tk.number(&intensity);
@@ -404,6 +448,7 @@ int crt_scene_file_load(const char* path, crt_scene_file** out)
     if (!sf) { fclose(fp); return CRT_E_NOMEM; }
     Loaded& L = sf->L;
     memset(&L.view, 0, sizeof L.view);
+    L.view.env_map_tex = -1;
     L.any_mesh = false;
     L.any_uv = false;
     {
@@ -431,7 +476,7 @@ int crt_scene_file_load(const char* path, crt_scene_file** out)
             else if (t == "ENV_LIGHT") parse_env_light(L, tk);
         }
     } catch (const std::bad_alloc&) {
-        fclose(fp); delete sf; return CRT_E_NOMEM;
+        fclose(fp); crt_scene_file_free(sf); return CRT_E_NOMEM;
     }
     fclose(fp);
     for (const std::string& s : L.names) L.name_ptrs.push_back(s.c_str());
@@ -451,12 +496,23 @@ int crt_scene_file_load(const char* path, crt_scene_file** out)
     V.mesh_shading.normal_mats = L.normal_mats.data();
     V.mesh_shading.num_normal_mats = (int32_t)(L.normal_mats.size() / 9);
     V.mesh_shading.vertex_uv = L.any_uv ? L.vertex_uv.data() : 0;
+    for (const std::string& n : L.tex_names) L.tex_name_ptrs.push_back(n.c_str());
+    V.num_textures = (int32_t)L.textures.size();
+    V.texture_names = L.tex_name_ptrs.data();
+    V.textures = L.textures.data();
+    V.material_diffuse_tex = L.mat_diffuse_tex.data();
+    V.material_normal_tex = L.mat_normal_tex.data();
     *out = sf;
     return CRT_OK;
 }
 
 const crt_scene_file_view* crt_scene_file_get(const crt_scene_file* sf) { return sf ? &sf->L.view : 0; }
-void crt_scene_file_free(crt_scene_file* sf) { delete sf; }
+void crt_scene_file_free(crt_scene_file* sf)
+{
+    if (!sf) return;
+    for (crt_texture& t : sf->L.textures) crt_texture_free(&t);
+    delete sf;
+}
 
 /* preprocessLights, buildscene.h:839-873: twice the diagonal of the accelerator's box -- with the QBVH branch as written
  * there (it starts from min = K_EPSILON, max = -HUGEVALUE and mixes components: box_min[2] takes min(., box_min[1]),

@@ -365,7 +365,8 @@ int  crt_primary_rays_dev(int device, const crt_camera* cam, const crt_film* fil
  *             (specular reflection, :129-136), TRANSPARENT (thin specular transmission, :137-141), PLASTIC (Fresnel-blend
  *             diffuse + specular lobes, :142-171), GLASS (rough dielectric, :172-178), METAL (:179-186), EMISSIVE; colours
  *             >= 0 and PLASTIC ks <= 1 (outside those bounds the reference paints paths BLUE / RED, trace.h:452-453,:478-479);
- *   textures  Matte.diffuse / Plastic.diffuse on FLAT_TRIANGLE / SMOOTH_TRIANGLE objects (crt_texture below); no normal maps;
+ *   textures  Matte.diffuse / Plastic.diffuse on FLAT_TRIANGLE / SMOOTH_TRIANGLE objects (interpolated texcoords) and on SPHERE /
+ *             RECTANGLE objects (the uv their intersectors write, sphere.cpp:14-19, rect.cpp:28-37) (crt_texture below); no normal maps;
  *   lights    area lights on RECTANGLE / SPHERE / DISK objects with an EMISSIVE material
  *             (initAreaLights, buildscene.h:567-608) and one EnvLight, constant or a lat-long map, behind EnvLight.transform;
  *             EMISSIVE triangles of any kind emit when a path finds them and are never sampled (the reference's MeshLights
@@ -431,7 +432,8 @@ typedef struct crt_render_desc {
     int32_t             num_textures;
     const int32_t*      material_diffuse_tex; /* [num_materials] index into textures[] or -1: Matte.diffuse / Plastic.diffuse
                                                  (materials.cpp:51-60,:146-149); honoured on FLAT_TRIANGLE / SMOOTH_TRIANGLE objects with
-                                                 mesh_shading->vertex_uv, anything else with a textured material is refused */
+                                                 mesh_shading->vertex_uv and on SPHERE / RECTANGLE objects; any other kind of object with
+                                                 a textured material is refused */
     int32_t             env_map;         /* 1 + index into textures[] of EnvLight.env_map (type TEXTURE, lights.cpp:238-247); 0 = type CONSTANT */
     float               env_transform[9];/* EnvLight.transform, row-major (buildscene.h:515: mat3_rotate_y(-0.76) for a map); all zero = identity */
     /* the part of the frame this renderer renders: image rows [row_begin, row_end), 0 / 0 = all.  The colour buffer then holds
@@ -531,7 +533,8 @@ int  crt_mesh_normals_tangents(const float* positions, int32_t num_vertices, con
  * OPENCYLINDER DISK TORUS SOLIDCYLINDER MESH), ENV_LIGHT.  Objects come out in file order as a crt_scene_input (meshes
  * loaded by crt_obj_load and flattened by crt_bake_mesh), materials as crt_material records, obj_material[i] = index
  * of object i's material (-1: the name is not defined, the reference's NULL).  The older grammar of the scene files
- * the reference ships (DIFF_COLOR / AMB_COLOR materials, no film header) is read too; textures are not loaded.
+ * the reference ships (DIFF_COLOR / AMB_COLOR materials, no film header) is read too; textures are bound by name and read
+ * where they are PPM files (see the view's texture fields).
  * Everything the view points to lives until crt_scene_file_free. */
 typedef struct crt_scene_file crt_scene_file;
 typedef struct crt_scene_file_view {
@@ -550,7 +553,22 @@ typedef struct crt_scene_file_view {
     int32_t             has_env_light;       /* an ENV_LIGHT entry; with intensity <= 0 it is no light and black (buildscene.h:525-533) */
     float               env_color[3], env_intensity;
     int32_t             num_skipped;         /* object entries dropped: unknown kind, no MATERIAL field, unreadable mesh file */
-    int32_t             num_unsupported;     /* textures, unknown material / metal types: kept as placeholders */
+    int32_t             num_unsupported;     /* unknown material / metal types (kept as placeholders), texture files that could not be read */
+    /* textures (TEXTURE / NORMAL_MAP of MATTE, scenefile.h:141-147,:161-171; KD_TEXTURE of PLASTIC, :225-233; ENV_LIGHT TYPE
+     * TEXTURE, buildscene.h:466-515), in order of first mention, one entry per file name (findTexture, scenedata.h:99-112,
+     * returns the first of that name).  Files are read with crt_texture_load_ppm, by the name given and then relative to
+     * the scene file; textures[i].data is NULL where that failed (counted in num_unsupported) and for the environment map,
+     * which the reference reads only from OpenEXR files (buildscene.h:478-483): its float texels are the caller's to supply
+     * (crt_render_desc.textures is the caller's array), counted in num_external. */
+    int32_t             num_textures;
+    const char* const*  texture_names;       /* [num_textures] */
+    const crt_texture*  textures;            /* [num_textures] */
+    const int32_t*      material_diffuse_tex;/* [num_materials] Matte.diffuse / Plastic.diffuse (linkMaterialTextures, buildscene.h:315-342) or -1 */
+    const int32_t*      material_normal_tex; /* [num_materials] Matte.normal_file_name or -1; the reference never applies it (buildscene.h:329) */
+    int32_t             env_type;            /* 0 CONSTANT, 1 TEXTURE (an .exr name; any other extension: CONSTANT and WHITE, buildscene.h:484-488) */
+    int32_t             env_map_tex;         /* index into textures[] of the map an ENV_LIGHT TYPE TEXTURE entry names, or -1 */
+    float               env_transform[9];    /* mat3_rotate_y(-0.76) for a TYPE TEXTURE entry (buildscene.h:515), else zero (= identity) */
+    int32_t             num_external;        /* named textures whose texels the caller supplies (the .exr environment map) */
 } crt_scene_file_view;
 int  crt_scene_file_load(const char* path, crt_scene_file** out);
 const crt_scene_file_view* crt_scene_file_get(const crt_scene_file* sf);
@@ -572,6 +590,11 @@ void crt_image_state_free(float* color_buffer);
 int  crt_image_from_color_buffer(unsigned char* image, const float* color_buffer, int num_pixels, int num_samples);
 /* PPM_write (imagefile.h:36-57): binary P6. */
 int  crt_ppm_write(const char* file_name, const unsigned char* image, int width, int height);
+/* PPM_read (imagefile.h:59-83), the one image reader the reference holds that needs no library it does not ship: binary P6,
+ * maxval 255, into a three-channel 8-bit crt_texture (rows top to bottom, as loadTexture leaves them).  out->data is malloc'd:
+ * release with crt_texture_free.  crt_scene_file_load reads the textures a scene file names through it. */
+int  crt_texture_load_ppm(const char* file_name, crt_texture* out);
+void crt_texture_free(crt_texture* t);
 
 /* Replaces intersect_call_count / shadow_intersect_call_count (intersect.h:363-364)
  * and g_intersect_count (shapes.cpp:3).  Counting is off by default (it costs atomics);

@@ -204,6 +204,12 @@ float simpleShapeRecord(const crt_shape& sh, const vec3 o, const vec3 d, float h
             vec3_normalize(sr->normal, hit_point_to_center);
             vec3_negate(sr->wo, d);
             const double phi_max = 2.0 * PI;
+            {                                                      /* sphere.cpp:14-19 */
+                const double theta_max = PI, theta_min = 0.0;
+                sr->uv[0] = (float)(phi / phi_max);
+                sr->uv[1] = (float)((theta - theta_min) / (theta_max - theta_min));
+                sr->has_uv = true;
+            }
             vec3_assign(sr->dpdu, -phi_max * (hit_point[2] - p[2]), 0.0f, phi_max * (hit_point[0] - p[0]));
             vec3_normalize(sr->dpdu, sr->dpdu);
             *has_normal = *has_dpdu = true;
@@ -511,6 +517,13 @@ void fillShadeRec(const Setup& S, ShadeRec* sr, const crt_ray& ray, const crt_hi
         if (vec3_dot(sr->wo, sr->normal) < 0.0f) {
             vec3_negate(sr->normal, sr->normal);
             vec3_negate(sr->dpdu, sr->dpdu);
+        }
+        {                                                          /* rect.cpp:22-37: the edge coordinates of the hit point */
+            vec3 d2;
+            vec3_sub(d2, sr->hit_point, p);
+            sr->uv[0] = vec3_dot(d2, p + 3) / vec3_dot(p + 3, p + 3);
+            sr->uv[1] = vec3_dot(d2, p + 6) / vec3_dot(p + 6, p + 6);
+            sr->has_uv = true;
         }
     } else {                                                       /* every other kind: the hit object's own intersector, re-run */
         bool has_normal = false, has_dpdu = false;

@@ -74,6 +74,10 @@ def test_textured_material_needs_texcoords():
     desc.material_diffuse_tex[0] = 7          # no such texture
     with pytest.raises(api.CrtError):
         api.Renderer(scene, desc, cam, flm)
+    desc.material_diffuse_tex[0] = -1
+    desc.material_diffuse_tex[3] = 0          # the sphere light's EMISSIVE material: not a material that reads a texture, accepted and ignored
+    api.Renderer(scene, desc, cam, flm).close()
+    scene.close()
 
 
 def test_counted_batches_read_the_ray_count_from_the_device():
@@ -104,3 +108,83 @@ def test_counted_batches_read_the_ray_count_from_the_device():
         assert torch.equal(got_t[:m].view(torch.int32), want_t[:m].view(torch.int32)) and bool((got_t[m:] == -7.0).all()), n
         assert torch.equal(got_o[:m], want_o[:m]) and bool((got_o[m:] == 9).all()), n
     sc.close()
+
+
+def test_c4_from_a_scene_file():
+    """tests/golden/scene_c4.txt (this repository's own file: a textured MATTE mesh with a named normal map, a
+    PLASTIC mesh with KD_TEXTURE, an ENV_LIGHT TYPE TEXTURE naming an .exr map) -> crt_scene_file_load (textures bound by name, PPM
+    files read by crt_texture_load_ppm) -> builder -> world radius -> renderer, the map's float texels supplied by the caller as the
+    loader asks: bit-identical to the oracle on the same description; nothing in the file is unsupported."""
+    import os
+    sf = api.SceneFile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_c4.txt"))
+    assert sf.num_unsupported == 0 and sf.num_skipped == 0 and sf.num_external == 1
+    sky = scenes.procedural_texture(128, 64, seed=15, is_float=True)
+    built = api.BuiltScene(sf.scene_input, api.ACCEL_BVH4)
+    desc = sf.render_desc(4, built=built, seed=5, texels={"c4_sky.exr": sky})
+    (pos, look), (_, _, w, h, fov) = sf.camera, sf.film
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, fov, w, h)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, desc, cam, flm)
+    r.render(4)
+    got, _ = r.read()
+    r.close()
+    want = ol.OracleScene(sf.scene_input, built=built).render(desc, cam, flm, 0, 4, nthreads=8)
+    assert np.isfinite(got).all() and got.max() > 0
+    assert ol.same_bits(got, want), "%.5f of the pixels are bit-identical" % (got == want).all(axis=2).mean()
+    assert got.std(axis=(0, 1)).min() > 0.05                       # textures and map are in the picture
+    # the same file with the map's texels swapped for a constant: a different image (the lookup is on the path)
+    flat = np.full_like(sky, 150.0)
+    d2 = sf.render_desc(4, built=built, seed=5, texels={"c4_sky.exr": flat})
+    r = api.Renderer(scene, d2, cam, flm)
+    r.render(4)
+    other, _ = r.read()
+    r.close(); scene.close()
+    assert (other != got).any(axis=2).mean() > 0.5
+
+
+def test_textured_spheres_and_rectangles():
+    """the sphere's and the rectangle's own intersectors write ShadeRec.uv (fillShadeRecSphere, sphere.cpp:14-19:
+    phi / 2 pi and theta / pi of the accepted root -- atan2's arguments differ between the two roots, so the inside of a sphere is
+    textured with another phi than the outside; rect.cpp:28-37: the edge coordinates), and Matte.diffuse / Plastic.diffuse read the
+    texel there (materials.cpp:51-60,:146-149).  A floor rectangle and a back-wall rectangle (textured MATTE / PLASTIC), a textured
+    sphere seen from outside, a partial textured sphere whose inside is seen through its opening, a rectangle light.
+    Against the oracle: the texcoords go through device atan2f / acosf, so a hit within rounding of a texel boundary may pick
+    the neighbouring texel (class T4) -- counted and bounded, like the window seams."""
+    sl = scenes.ShapeList()
+    mat_of = []
+    sl.rectangle((-2.0, 0.0, -2.0), (4.0, 0.0, 0.0), (0.0, 0.0, 4.0)); mat_of.append(0)          # floor
+    sl.rectangle((-2.0, 0.0, -2.0), (4.0, 0.0, 0.0), (0.0, 2.5, 0.0)); mat_of.append(1)          # back wall
+    sl.sphere((-0.6, 0.5, 0.0), 0.5); mat_of.append(2)
+    sl.sphere((0.7, 0.45, 0.3), 0.45, min_theta=0.9, max_theta=3.14159, phi=3.14159); mat_of.append(3)   # open at the top
+    sl.rectangle((-0.5, 2.2, 0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0)); mat_of.append(4)           # light
+    si = sl.to_input()
+    mats = np.array([api.material(api.MAT_MATTE, (1.0, 1.0, 1.0)), api.material(api.MAT_PLASTIC, (1.0, 1.0, 1.0), ks=(0.2, 0.2, 0.2), uroughness=0.2),
+                     api.material(api.MAT_MATTE, (1.0, 1.0, 1.0), sigma=20.0), api.material(api.MAT_PLASTIC, (1.0, 1.0, 1.0), ks=(0.3, 0.3, 0.3), uroughness=0.1),
+                     api.material(api.MAT_EMISSIVE, (1.0, 0.95, 0.9), 12.0)], api.MATERIAL_DTYPE)
+    textures = [scenes.procedural_texture(64, 64, seed=21), scenes.procedural_texture(32, 48, seed=22), scenes.procedural_texture(48, 24, seed=23)]
+    desc = api.RenderDesc(si, mat_of, mats, 4, seed=11, env=((0.5, 0.6, 0.8), 0.3, 12.0), textures=textures,
+                          material_diffuse_tex=[0, 1, 2, 1, -1])
+    cam = api.make_camera((0.2, 1.6, 3.2), (0.0, 0.5, 0.0), focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.0, 160, 120)
+    for accel in (api.ACCEL_BVH4, api.ACCEL_GRID):
+        built = api.BuiltScene(si, accel)
+        scene = api.Scene(built)
+        r = api.Renderer(scene, desc, cam, flm)
+        r.render(4)
+        got, _ = r.read()
+        r.close(); scene.close()
+        want = ol.OracleScene(si, built=built).render(desc, cam, flm, 0, 4, nthreads=8)
+        assert np.isfinite(got).all() and got.max() > 0
+        differ = (got != want).any(axis=2)
+        assert differ.mean() <= 0.002, "%d of %d pixels differ from the oracle" % (int(differ.sum()), differ.size)      # class T4
+        assert got.std(axis=(0, 1)).min() > 0.03                   # the checkers are in the picture
+    # plain colours instead: a different image, i.e. the lookups happen
+    flat = api.RenderDesc(si, mat_of, mats, 4, seed=11, env=((0.5, 0.6, 0.8), 0.3, 12.0))
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    scene = api.Scene(built)
+    r = api.Renderer(scene, flat, cam, flm)
+    r.render(4)
+    plain, _ = r.read()
+    r.close(); scene.close()
+    assert (plain != got).any(axis=2).mean() > 0.5

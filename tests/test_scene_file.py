@@ -149,3 +149,71 @@ def test_env_world_radius(accel):
     with pytest.raises(api.CrtError) as e:
         api.env_world_radius(api.BuiltScene(si, api.ACCEL_NONE))
     assert e.value.code == -4
+
+
+def test_textures_are_bound_by_name_and_ppm_files_are_read():
+    """tests/golden/scene_c4.txt (this repository's own file; assets by make_scene_c4.py): TEXTURE / NORMAL_MAP of a MATTE entry
+    (scenefile.h:141-171), KD_TEXTURE of a PLASTIC entry (:225-233), ENV_LIGHT TYPE TEXTURE with an .exr name
+    (buildscene.h:466-515).  Names in order of first mention, materials linked to them as linkMaterialTextures does
+    (buildscene.h:315-342), PPM files read, the .exr map named and left to the caller."""
+    sf = api.SceneFile(os.path.join(GOLD, "scene_c4.txt"))
+    assert sf.num_skipped == 0 and sf.num_unsupported == 0 and sf.num_external == 1
+    assert sf.texture_names == ["c4_tex_a.ppm", "c4_normal.ppm", "c4_tex_b.ppm", "c4_sky.exr"]
+    assert sf.material_names == ["floor", "cloth", "shell", "lamp"]
+    assert sf.material_diffuse_tex.tolist() == [-1, 0, 2, -1] and sf.material_normal_tex.tolist() == [-1, 1, -1, -1]
+    assert sf.env_type == 1 and sf.env_map_tex == 3 and sf.env_light == ((1.0, 1.0, 1.0), 1.0)
+    s, c = np.sin(np.float32(-0.76)), np.cos(np.float32(-0.76))                                # mat3_rotate_y(-0.76), util/mat.h:229-238
+    assert np.allclose(sf.env_transform, np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32), atol=1e-7)
+    assert sf.textures[3] is None
+    for k, (w, h, seed) in {0: (32, 32, 13), 2: (16, 32, 14), 1: (8, 8, 16)}.items():           # the texels make_scene_c4.py wrote
+        assert sf.textures[k].dtype == np.uint8 and np.array_equal(sf.textures[k], scenes.procedural_texture(w, h, seed=seed))
+    # the two meshes carry the OBJ's texture coordinates, which run past 1
+    uv = sf.mesh_shading.vertex_uv
+    assert uv is not None and uv.shape == (len(sf.scene_input.tri_verts), 6)
+    assert uv[2:].max() > 1.5 and uv[2:].min() < 0.0 and np.all(uv[:2] == 0)
+    assert sf.scene_input.num_obj == 2 + 2 * 576 + 1
+    # a description needs the map's texels from the caller
+    with pytest.raises(ValueError):
+        sf.render_desc(4, world_radius=6.0)
+    sky = scenes.procedural_texture(128, 64, seed=15, is_float=True)
+    d = sf.render_desc(4, world_radius=6.0, texels={"c4_sky.exr": sky})
+    assert d.c.num_textures == 4 and d.c.env_map == 4 and d.material_diffuse_tex.tolist() == [-1, 0, 2, -1]
+
+
+def test_texture_entries_of_other_kinds(tmp_path):
+    """An environment map that is not an .exr file is CONSTANT and WHITE (buildscene.h:484-488); a texture file that is missing
+    or not a PPM leaves an entry without texels and is counted; one name mentioned twice is one entry (findTexture returns the
+    first of that name); KD_TEXTURE on a material that linkMaterialTextures does not link is not linked."""
+    api.ppm_write(str(tmp_path / "a.ppm"), scenes.procedural_texture(4, 6, seed=1))
+    (tmp_path / "bad.ppm").write_bytes(b"P3\n2 2\n255\n" + bytes(12))
+    (tmp_path / "short.ppm").write_bytes(b"P6\n4 4\n255\n" + bytes(10))
+    (tmp_path / "s.txt").write_text(
+        "MATERIAL MATTE NAME m0 TEXTURE a.ppm SIGMA 0 END\n"
+        "MATERIAL MATTE NAME m1 TEXTURE a.ppm SIGMA 0 NORMAL_MAP missing.png END\n"
+        "MATERIAL PLASTIC NAME m2 KD_TEXTURE bad.ppm KS 0.1 0.1 0.1 ROUGHNESS 0.2 END\n"
+        "MATERIAL PLASTIC NAME m3 KD_TEXTURE short.ppm KS 0.1 0.1 0.1 ROUGHNESS 0.2 END\n"
+        "MATERIAL MIRROR NAME m4 COLOR WHITE TEXTURE a.ppm END\n"
+        "END_MATERIALS\n"
+        "ENV_LIGHT TYPE TEXTURE COLOR sky.hdr INTENSITY 2.0\n"
+        "OBJECT TRIANGLE V0 0 0 0 V1 1 0 0 V2 0 1 0 MATERIAL m0\n")
+    sf = api.SceneFile(str(tmp_path / "s.txt"))
+    assert sf.texture_names == ["a.ppm", "missing.png", "bad.ppm", "short.ppm"]
+    assert sf.textures[0].shape == (6, 4, 3) and sf.textures[1] is None and sf.textures[2] is None and sf.textures[3] is None
+    assert sf.num_unsupported == 3 and sf.num_external == 0
+    assert sf.material_diffuse_tex.tolist() == [0, 0, 2, 3, -1] and sf.material_normal_tex.tolist() == [-1, 1, -1, -1, -1]
+    assert sf.env_type == 0 and sf.env_map_tex == -1 and sf.env_light == ((1.0, 1.0, 1.0), 2.0)
+
+
+def test_ppm_reader(tmp_path):
+    """crt_texture_load_ppm (PPM_read, imagefile.h:59-83) reads back what crt_ppm_write (PPM_write, :36-57) wrote, byte for byte --
+    also when the first pixel byte is a white-space character, which the reference's fscanf("%d\\n") would swallow."""
+    img = scenes.procedural_texture(7, 5, seed=3)
+    img[0, 0] = (0x20, 0x0A, 0x09)
+    p = str(tmp_path / "t.ppm")
+    api.ppm_write(p, img)
+    assert np.array_equal(api.texture_load_ppm(p), img)
+    with pytest.raises(api.CrtError):
+        api.texture_load_ppm(str(tmp_path / "nothing.ppm"))
+    (tmp_path / "p5.ppm").write_bytes(b"P5\n2 2\n255\n" + bytes(4))
+    with pytest.raises(api.CrtError):
+        api.texture_load_ppm(str(tmp_path / "p5.ppm"))
