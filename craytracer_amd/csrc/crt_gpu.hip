@@ -1025,8 +1025,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         if (!hip_ok(hipMemset(sx.bin_hist, 0, CRT_BIN_CELLS * sizeof(unsigned)), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     }
     for (int k = 0; k < CRT_SLOTS; k++) if (!s->own[k].fb_list) s->wide8_valid = false;       /* no list, no 8-wide walk */
-    if (!hip_ok(hipMalloc((void**)&s->d_counters, 256), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }
-    if (!hip_ok(hipMemset(s->d_counters, 0, 256), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
+    if (!hip_ok(hipMalloc((void**)&s->d_counters, 512), "hipMalloc")) { free_scene(s); return CRT_E_NOMEM; }     /* 4 counters + the diagnostic build's */
+    if (!hip_ok(hipMemset(s->d_counters, 0, 512), "hipMemset")) { free_scene(s); return CRT_E_HIP; }
     for (int k = 0; k < CRT_TIMING_RING; k++) {
         LaunchTiming& lt = s->ring[k];
         if (!hip_ok(hipEventCreate(&lt.ev_bin), "hipEventCreate")) { free_scene(s); return CRT_E_HIP; }
@@ -1468,6 +1468,16 @@ int crt_scene_get_counters(crt_scene* s, crt_counters* out)
                 d[6] ? (double)d[9] / d[6] : 0.0, d[6] ? (double)d[10] / d[6] : 0.0);
     }
 #endif
+#if CRT_TIMELINE
+    {
+            unsigned long long w[8];
+            HIPCHK(hipMemcpy(w, s->d_counters + 32, sizeof w, hipMemcpyDeviceToHost));
+            const double first = (double)(~w[0]), tick = 1.0e-5;      /* 100 MHz -> ms */
+            fprintf(stderr, "[diag] timeline of the LAST counted launch only if counters were reset before it (ms after the first wave started): waves start until %.4f; queue dry for the first wave at %.4f, for the last at %.4f; first wave ends at %.4f, last at %.4f; mean tail of a wave %.4f (%llu waves)\n",
+                    ((double)w[1] - first) * tick, ((double)(~w[2]) - first) * tick, ((double)w[3] - first) * tick,
+                    ((double)(~w[4]) - first) * tick, ((double)w[5] - first) * tick, w[7] ? (double)w[6] / (double)w[7] * tick : 0.0, w[7]);
+        }
+#endif
     return CRT_OK;
 }
 int crt_scene_reset_counters(crt_scene* s)
@@ -1476,7 +1486,7 @@ int crt_scene_reset_counters(crt_scene* s)
     DeviceGuard guard(s->device);
     if (!guard.ok) return CRT_E_HIP;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(s->d_counters, 0, 256));
+    HIPCHK(hipMemset(s->d_counters, 0, 512));
     return CRT_OK;
 }
 /* The calling thread's most recent launch through `s`: its slot of the timing ring, if it is still there. */

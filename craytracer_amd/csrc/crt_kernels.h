@@ -370,6 +370,9 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #ifndef CRT_DIAG
 #define CRT_DIAG 0                /* diagnostic build: per-iteration lane statistics of the closest-hit walk into counters[8..] */
 #endif
+#ifndef CRT_TIMELINE
+#define CRT_TIMELINE 0            /* diagnostic build: when each wave of the closest-hit walk started, ran dry and ended, into counters[32..] */
+#endif
 /* ordering of the tail-splitting slots (LDS, touched by the lanes of one wave only) */
 #define CRT_WG_FENCE()    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 #ifndef CRT_STEAL_BOTTOM
@@ -380,6 +383,9 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #endif
 #ifndef CRT_PENDING_LEAF
 #define CRT_PENDING_LEAF 1
+#endif
+#ifndef CRT_SPLIT_MIN_IDLE
+#define CRT_SPLIT_MIN_IDLE 8      /* tail splitting: idle lanes a hand-over round waits for */
 #endif
 
 CRT_DEV unsigned lane_rank(unsigned long long mask)
@@ -647,6 +653,11 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
     unsigned d_tail_it = 0, d_tail_alive = 0, d_steals = 0;
     unsigned d_uniform = 0, d_distinct = 0;      /* node-step iterations whose lanes all visit ONE node; distinct nodes per node-step iteration, summed */
 #endif
+#if CRT_TIMELINE
+    /* wall clock (100 MHz, one counter for the whole device) when this wave started, when its queue ran dry, when it ended */
+    const unsigned long long d_t0 = wall_clock64();
+    unsigned long long d_tdry = 0ull;
+#endif
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
         if (idle != 0ull && !feed.empty && __popcll(idle) >= CRT_REFILL_MIN) {
@@ -677,7 +688,9 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
             if (can_give) can_give = !(s_stack[st.sp - 1][threadIdx.x].x & CRT_LEAF_BIT);
 #endif
             const unsigned long long give_m = __ballot(can_give), idle_m = __ballot(!alive);
-            if (give_m != 0ull && idle_m != 0ull) {
+            /* a hand-over round costs the whole wave about as much as an iteration of the walk (ballots, a rank search, a
+             * dozen lane permutes, the slot's atomics), so rounds are held until CRT_SPLIT_MIN_IDLE lanes are idle */
+            if (give_m != 0ull && __popcll(idle_m) >= CRT_SPLIT_MIN_IDLE) {
                 const unsigned n_give = (unsigned)__popcll(give_m), n_idle = (unsigned)__popcll(idle_m);
                 const unsigned n_pair = n_give < n_idle ? n_give : n_idle;
                 const unsigned lane = threadIdx.x & 63u;
@@ -722,6 +735,9 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
                 CRT_TAKE_F(ray.ox) CRT_TAKE_F(ray.oy) CRT_TAKE_F(ray.oz) CRT_TAKE_F(ray.dx) CRT_TAKE_F(ray.dy) CRT_TAKE_F(ray.dz)
                 const float v_bt = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(best_t)));
                 const unsigned v_grp = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)grp);
+                /* what start_ray derives from the ray comes along too (three correctly rounded divisions otherwise) */
+                CRT_TAKE_F(ia) CRT_TAKE_F(ib) CRT_TAKE_F(ic)
+                const unsigned v_flags = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)(pbits | (clean ? 8u : 0u)));
                 CRT_TAKE_U(e_w) CRT_TAKE_U(e_k)
                 #undef CRT_TAKE_U
                 #undef CRT_TAKE_F
@@ -729,7 +745,17 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
                 if (COUNT) d_steals += n_pair;
 #endif
                 if (taking) {
-                    start_ray();
+                    {
+                        const bool sx = ray.dx >= 0.0f, sy = ray.dy >= 0.0f, sz = ray.dz >= 0.0f;
+                        onx = sx ? 0u : 48u;  ofx = 48u - onx;
+                        ony = sy ? 16u : 64u; ofy = 80u - ony;
+                        onz = sz ? 32u : 80u; ofz = 112u - onz;
+                        pbits = v_flags & 7u; px = (pbits & 1u) != 0u; clean = (v_flags & 8u) != 0u;
+                        cur_min = CRT_TMAX;
+                        best.obj = -1; best.part = -1; best.beta = 0.0f; best.gamma = 0.0f;
+                        st.sp = 0; pl = 0u;
+                        alive = true;
+                    }
                     grp = v_grp & 0x3FFFu;
                     best_t = v_bt;                                   /* a bound to prune with; `best` stays empty until this piece finds a hit */
                     cur = e_w;
@@ -739,6 +765,9 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
             }
         }
         if (__ballot(alive) == 0ull) break;           /* nothing in flight: the queue is drained */
+#if CRT_TIMELINE
+        if (COUNT && feed.empty && d_tdry == 0ull) d_tdry = wall_clock64();
+#endif
 #if CRT_DIAG
         if (COUNT && feed.empty) { d_tail_it++; d_tail_alive += (unsigned)__popcll(__ballot(alive)); }
         if (COUNT && alive) d_ray_it++;
@@ -863,6 +892,17 @@ CRT_DEV void bvh4_closest_body(DevScene sc, LaunchArgs la)
         atomicMax(&sc.counters[7], (unsigned long long)d_tail_it);
         atomicAdd(&sc.counters[17], (unsigned long long)d_uniform);
         atomicAdd(&sc.counters[18], (unsigned long long)d_distinct);
+    }
+#endif
+#if CRT_TIMELINE
+    if (COUNT && (threadIdx.x & 63) == 0) {
+        const unsigned long long d_t1 = wall_clock64();
+        if (d_tdry == 0ull) d_tdry = d_t1;
+        atomicMax(&sc.counters[32], ~d_t0);   atomicMax(&sc.counters[33], d_t0);       /* first / last wave start */
+        atomicMax(&sc.counters[34], ~d_tdry); atomicMax(&sc.counters[35], d_tdry);     /* first / last queue-dry */
+        atomicMax(&sc.counters[36], ~d_t1);   atomicMax(&sc.counters[37], d_t1);       /* first / last wave end */
+        atomicAdd(&sc.counters[38], d_t1 - d_tdry);                                     /* summed tail time of the waves */
+        atomicAdd(&sc.counters[39], 1ull);
     }
 #endif
 }

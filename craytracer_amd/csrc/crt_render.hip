@@ -786,6 +786,8 @@ struct crt_renderer {
     uint64_t samples;
     crt_render_stats stats;
     hipStream_t stream;
+    hipStream_t stream2; bool stream2_valid;          /* the shadow query and the accumulation of a bounce run here, beside the next bounce's extend query */
+    std::vector<hipEvent_t> ev_sync;                  /* 2 per bounce launched in a pass: shade done (stream), accumulate done (stream2) */
     std::vector<void*> allocs;
     /* the host follows the device two bounces behind: the queue sizes of each bounce land here (page-locked) */
     uint32_t* h_counts; size_t counts_words;
@@ -832,6 +834,8 @@ void crt_renderer_destroy(crt_renderer* r)
     for (void* p : r->allocs) (void)hipFree(p);
     for (hipEvent_t e : r->ev_count) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->ev_time) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->ev_sync) (void)hipEventDestroy(e);
+    if (r->stream2_valid) (void)hipStreamDestroy(r->stream2);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
     delete r;
 }
@@ -987,7 +991,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (scene_objs != in->num_obj) return CRT_E_INVALID;          /* hit ids index the per-object tables built above */
     crt_renderer* r = new (std::nothrow) crt_renderer();
     if (!r) return CRT_E_NOMEM;
-    r->scene = scene; r->device = device; r->samples = 0; r->stream = 0;
+    r->scene = scene; r->device = device; r->samples = 0; r->stream = 0; r->stream2 = 0; r->stream2_valid = false;
     r->h_counts = 0; r->counts_words = 0;
     memset(&r->stats, 0, sizeof r->stats);
     memset(&r->rd, 0, sizeof r->rd);
@@ -1101,6 +1105,7 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     ok = ok && hipMemset(rd.color, 0, 3 * (size_t)npix * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(rd.counters, 0, r->counts_words * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipStreamCreate(&r->stream) == hipSuccess;
+    if (ok) { r->stream2_valid = hipStreamCreate(&r->stream2) == hipSuccess; ok = r->stream2_valid; }
     if (!ok) { crt_renderer_destroy(r); return rc != CRT_OK ? rc : CRT_E_HIP; }
     rd.objs = d_objs; rd.mats = d_mats; rd.lights = d_lights;
     rd.vnormals = d_vn; rd.vtangents = d_vt; rd.normal_mats = d_nm;
@@ -1144,31 +1149,53 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
         if (hipMemsetAsync(rd.counters, 0, r->counts_words * sizeof(uint32_t), st) != hipSuccess) return CRT_E_HIP;
         hipLaunchKernelGGL(k_pt_generate, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, first_sample);
         int cur = 0, launched = 0;
+        /* Two streams (round 3).  Within a bounce: extend -> shade on `st`; shadow -> accumulate on `st2`, after the shade that
+         * filled the shadow queue.  The next bounce's extend query needs only the shade's ray queue, so it runs beside this
+         * bounce's shadow query (the scene keeps two sets of launch scratch); the next SHADE waits for this bounce's
+         * accumulate -- both add to L and good_paths of the same paths, in the reference's order (emitted light of bounce
+         * b + 1 after the direct light of bounce b, trace.h:419-480), and by then the shadow queue is free again.
+         * n_bound: the host follows the queue sizes two bounces behind; a bounce's queues are never longer than the ray queue
+         * of the bounce before it, so that count bounds (and sizes) this bounce's launches -- small late bounces get small
+         * grids and the walk instance the library keeps for small batches. */
+        hipStream_t st2 = r->stream2;
         for (int bounce = 0; bounce <= rd.max_depth; bounce++) {
+            unsigned n_bound = P;
             if (bounce >= 2) {
                 if (hipEventSynchronize(r->ev_count[(bounce - 2) & 3]) != hipSuccess) return CRT_E_HIP;
                 if (r->h_counts[2 * (bounce - 1)] == 0) break;                /* bounce - 2 queued nothing: the pass is over */
+                if (r->h_counts[2 * (bounce - 1)] < n_bound) n_bound = r->h_counts[2 * (bounce - 1)];
             }
             while (r->ev_time.size() < 4 * (size_t)(bounce + 1)) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) != hipSuccess) return CRT_E_HIP;
                 r->ev_time.push_back(e);
             }
+            while (r->ev_sync.size() < 2 * (size_t)(bounce + 1)) {
+                hipEvent_t e;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CRT_E_HIP;
+                r->ev_sync.push_back(e);
+            }
             hipEvent_t* ev = &r->ev_time[4 * (size_t)bounce];
+            hipEvent_t* sy = &r->ev_sync[2 * (size_t)bounce];
             if (hipEventRecord(ev[0], st) != hipSuccess) return CRT_E_HIP;
-            int rc = crt_intersect_batch_dev_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, P, rd.hits, st);
+            int rc = crt_intersect_batch_dev_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, n_bound, rd.hits, st);
             if (rc != CRT_OK) return rc;
             if (hipEventRecord(ev[1], st) != hipSuccess) return CRT_E_HIP;
-            hipLaunchKernelGGL(k_pt_shade, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, bounce, cur, first_sample);
+            if (bounce > 0 && hipStreamWaitEvent(st, r->ev_sync[2 * (size_t)(bounce - 1) + 1], 0) != hipSuccess) return CRT_E_HIP;   /* accumulate(bounce - 1) */
+            hipLaunchKernelGGL(k_pt_shade, dim3((n_bound + 255) / 256), dim3(256), 0, st, rd, n_bound, bounce, cur, first_sample);
             if (hipMemcpyAsync(r->h_counts + 2 * (bounce + 1), rd.counters + 2 * (bounce + 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess) return CRT_E_HIP;
             if (hipEventRecord(r->ev_count[bounce & 3], st) != hipSuccess) return CRT_E_HIP;
-            if (hipEventRecord(ev[2], st) != hipSuccess) return CRT_E_HIP;
-            rc = crt_shadow_batch_dev_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, P, 0, rd.socc, st);
+            if (hipEventRecord(sy[0], st) != hipSuccess) return CRT_E_HIP;
+            if (hipStreamWaitEvent(st2, sy[0], 0) != hipSuccess) return CRT_E_HIP;
+            if (hipEventRecord(ev[2], st2) != hipSuccess) return CRT_E_HIP;
+            rc = crt_shadow_batch_dev_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, n_bound, 0, rd.socc, st2);
             if (rc != CRT_OK) return rc;
-            if (hipEventRecord(ev[3], st) != hipSuccess) return CRT_E_HIP;
-            hipLaunchKernelGGL(k_pt_accumulate, dim3((P + 255) / 256), dim3(256), 0, st, rd, P, bounce);
+            if (hipEventRecord(ev[3], st2) != hipSuccess) return CRT_E_HIP;
+            hipLaunchKernelGGL(k_pt_accumulate, dim3((n_bound + 255) / 256), dim3(256), 0, st2, rd, n_bound, bounce);
+            if (hipEventRecord(sy[1], st2) != hipSuccess) return CRT_E_HIP;
             cur ^= 1; launched++;
         }
+        if (launched > 0 && hipStreamWaitEvent(st, r->ev_sync[2 * (size_t)(launched - 1) + 1], 0) != hipSuccess) return CRT_E_HIP;
         hipLaunchKernelGGL(k_pt_finish, dim3((rd.npix + 255) / 256), dim3(256), 0, st, rd, spp, first_sample);
         if (hipGetLastError() != hipSuccess) return CRT_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return CRT_E_HIP;

@@ -47,8 +47,17 @@ def test_qbvh_walks_against_the_reference_binary(scene):
         # any hit: the t reported is that of the first hit found below light_dist, a property of the tree's visiting order; whether
         # the ray is occluded is a property of the scene EXCEPT in class T5: a first-found hit inside
         # [light_dist - K_EPSILON, light_dist) ends the walk and reads "not occluded" even if a nearer occluder comes later in the order
-        if not sah:
+        if not sah and scene == "soup20k":
+            # distinct centroids: the product's builder makes the reference's tree node for node, so the walk order is the same
             assert ol.same_bits(g_t, r_t) and np.array_equal(g_occ, r_occ)
+        elif not sah:
+            # the blobs hold triangles with EQUAL centroids along a split axis; the reference orders those by an unstable quicksort
+            # whose pivots come from rand() (bvh.h:56-83), the product by a stable sort: two valid median-split trees, so the first
+            # hit FOUND differs on a few per cent of the rays (984 of 32 768 for the oracle on the same tree) while what is
+            # occluded does not
+            assert np.array_equal(g_occ, r_occ)
+            assert np.all((g_t < ld) == (r_t < ld))
+            assert 0 < (g_t.view(np.uint32) != r_t.view(np.uint32)).sum() < len(ld) // 10
         else:
             d = g_occ != r_occ
             ldd = ld[d]

@@ -107,3 +107,37 @@ def test_the_limit_itself_and_two_scenes_taking_turns():
     assert ol.same_bits(got_a2, want_a[:4097]) and ol.same_bits(want_a2, want_a[:4097])
     sa.close()
     sb.close()
+
+
+def test_two_scenes_on_two_streams_without_a_sync_between():
+    """every no-allocation launch on a GPU shares that GPU's array, whichever scene it comes through, so the library
+    orders them per DEVICE (one library-owned event).  Two scenes, two streams, launches alternating with no host
+    synchronisation in between: each output equals that scene's crt_intersect_batch_dev output."""
+    import torch
+    si_a = scenes.courtyard(8, 32, 64, seed=6)
+    si_b = scenes.buddha_like(64, 128, seed=8)
+    sa = api.Scene(api.BuiltScene(si_a, api.ACCEL_BVH4, sah=True), 0)
+    sb = api.Scene(api.BuiltScene(si_b, api.ACCEL_BVH4), 0)
+    n = 1 << 20
+    da = _dev_rays(torch, scenes.random_rays(n, *scenes.scene_bounds(si_a), seed=31))
+    db = _dev_rays(torch, scenes.random_rays(n, *scenes.scene_bounds(si_b), seed=32))
+    want_a = torch.empty((n, 5), dtype=torch.int32, device="cuda")
+    want_b = torch.empty((n, 5), dtype=torch.int32, device="cuda")
+    sa.intersect_dev(da.data_ptr(), n, want_a.data_ptr(), None)
+    sb.intersect_dev(db.data_ptr(), n, want_b.data_ptr(), None)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(6):
+        ga = torch.full((n, 5), -9, dtype=torch.int32, device="cuda")
+        gb = torch.full((n, 5), -9, dtype=torch.int32, device="cuda")
+        outs.append((ga, gb))
+    torch.cuda.synchronize()
+    for ga, gb in outs:                                            # no synchronisation inside this loop
+        sa.intersect_dev_noalloc(da.data_ptr(), n, ga.data_ptr(), s1.cuda_stream)
+        sb.intersect_dev_noalloc(db.data_ptr(), n, gb.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    for ga, gb in outs:
+        assert torch.equal(ga, want_a) and torch.equal(gb, want_b)
+    sa.close()
+    sb.close()
