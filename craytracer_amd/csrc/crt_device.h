@@ -466,20 +466,24 @@ __device__ __noinline__ float dev_shape(const crt_shape* shapes, int si, const D
 
 /* rayIntersectObject on final-order object `oi` (shapes/shapes.cpp:4-48).
  * TRI_ONLY kernels never take the shape branch. */
-template <bool TRI_ONLY>
+/* KIND: which object types the scene holds, known on the host -- 0 any, 1 (= true) triangles only, 2 triangles and rectangles
+ * (CRT_KIND_TRI_RECT: config C1's cornell box; a kernel of that kind never references the analytic shapes, whose f64 quartic
+ * and libm calls cost every other instance its registers) */
+#define CRT_KIND_TRI_RECT 2
+template <int KIND>
 CRT_DEV float dev_object_rec(const DevScene& sc, const float4* rec, const DRay& ray, bool shadow, DHit* h)
 {
     float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     h->obj = __float_as_int(r2.y);
     h->part = 0;
-    if (TRI_ONLY || dev_is_tri(__float_as_int(r2.z)))
+    if (KIND == 1 || dev_is_tri(__float_as_int(r2.z)))
         return dev_tri(r0, r1, r2, ray, &h->beta, &h->gamma);
     h->beta = 0.0f; h->gamma = 0.0f;
     /* rectangles in line: cornell_box.txt (config C1) is rectangles and triangles, and the general path is two out-of-line calls */
-    if (__float_as_int(r2.z) == CRT_RECTANGLE) return dev_rect(sc.shapes[__float_as_int(r2.w)].p, ray, shadow);
+    if (KIND == CRT_KIND_TRI_RECT || __float_as_int(r2.z) == CRT_RECTANGLE) return dev_rect(sc.shapes[__float_as_int(r2.w)].p, ray, shadow);
     return dev_shape(sc.shapes, __float_as_int(r2.w), ray, shadow, &h->part);
 }
-template <bool TRI_ONLY>
+template <int TRI_ONLY>
 CRT_DEV float dev_object(const DevScene& sc, int oi, const DRay& ray, bool shadow, DHit* h)
 {
     return dev_object_rec<TRI_ONLY>(sc, sc.objs + (size_t)oi * CRT_OBJ_STRIDE, ray, shadow, h);

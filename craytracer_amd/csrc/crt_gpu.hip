@@ -76,6 +76,7 @@ struct crt_scene {
     unsigned long long uid;   /* distinguishes scenes that reuse an address (thread-local launch tokens) */
     DevScene dev;
     bool tri_only;            /* every object is a triangle type */
+    bool tri_rect_only;       /* every object is a triangle type or a RECTANGLE (and not all are triangles) */
     bool accel_tri_only;      /* every object below the accelerator is a triangle type */
     bool accel_bounded;       /* ... or another shape whose box bounds it: sphere, rectangle, disk (shapes.cpp:146-263) */
     int depth4, depth2;       /* levels of the QBVH / BVH */
@@ -687,8 +688,15 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, LaunchO
     case CRT_ACCEL_GRID: /* lane refill pays for incoherent closest-hit rays through triangles (735 -> 1 229 Mrays/s); the any-hit walk
                             (694 plain, 637 with refill) and the all-shapes instance (C1: 7.1 against 8.7 ms) keep the plain loop */
                          o.max_blocks = CRT_GRID_BLOCKS;
-                         if constexpr (TRI_ONLY) return launch(s, k_grid_refill<true, COUNT, false>, la, st, o);
-                         else return launch(s, k_grid<false, COUNT, false>, la, st, o);
+                         if constexpr (TRI_ONLY) return launch(s, k_grid_refill<1, COUNT, false>, la, st, o);
+                         else {
+                             /* triangles and rectangles only (config C1, the cornell box): an instance of the plain walk that never
+                              * references the analytic shapes -- 56-60 VGPRs and no scratch against 137 + 256 bytes of spills, seven
+                              * waves per SIMD against three.  C1 6.46 -> 5.90 ms; the lane-refill form measured 6.21 (a scene of 29
+                              * objects in 1 000 cells is all arithmetic, and coherent rays keep a wave's lanes in step) */
+                             if (s->tri_rect_only) return launch(s, k_grid<CRT_KIND_TRI_RECT, COUNT, false>, la, st, o);
+                             return launch(s, k_grid<0, COUNT, false>, la, st, o);
+                         }
     default:             o.use_binning = false;
                          return launch(s, k_none_closest<TRI_ONLY, COUNT>, la, st, o);
     }
@@ -707,7 +715,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st, unsigned
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, o)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, o);
     case CRT_ACCEL_GRID: o.max_blocks = CRT_GRID_BLOCKS;
-                         return launch(s, k_grid<TRI_ONLY, COUNT, true>, la, st, o);
+                         if constexpr (!TRI_ONLY) { if (s->tri_rect_only) return launch(s, k_grid<CRT_KIND_TRI_RECT, COUNT, true>, la, st, o); }
+                         return launch(s, k_grid<TRI_ONLY ? 1 : 0, COUNT, true>, la, st, o);
     default:             o.use_binning = false;
                          return launch(s, k_none_shadow<TRI_ONLY, COUNT>, la, st, o);
     }
@@ -784,6 +793,15 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             objs[(size_t)i*CRT_OBJ_STRIDE + 2] = make_float4(v[8], idf, tf, rf);
         }
         s->tri_only = all_tri;
+        {
+            bool tr = !all_tri;
+            for (int i = 0; i < n && tr; i++) {
+                const int t = desc->obj_type[i];
+                if (!(t == CRT_TRIANGLE || t == CRT_FLAT_TRIANGLE || t == CRT_SMOOTH_TRIANGLE || t == CRT_RECTANGLE)) tr = false;
+            }
+            const char* e = getenv("CRT_GRID_TRI_RECT");                  /* A/B knob: 0 = the all-shapes instance */
+            s->tri_rect_only = tr && !(e && atoi(e) == 0);
+        }
         s->accel_tri_only = accel_tri;
         s->accel_bounded = accel_bounded;
         s->depth4 = d4; s->depth2 = d2;

@@ -317,7 +317,7 @@ CRT_DEV void cnode_keys_regs(const uint4 c0, const uint4 c1, const uint4 c2, con
 
 /* Linear pass over objects[first, last) -- the non-grid loops of intersectTest
  * (intersect.h:387-395,:403-411) and the NONE branch (:416-432): strict `<`. */
-template <bool TRI_ONLY, bool COUNT>
+template <int TRI_ONLY, bool COUNT>
 CRT_DEV void linear_closest(const DevScene& sc, int first, int last, const DRay& ray, float* best_t, DHit* best, unsigned* prims)
 {
     for (int i = first; i < last; i++) {
@@ -328,7 +328,7 @@ CRT_DEV void linear_closest(const DevScene& sc, int first, int last, const DRay&
     }
 }
 /* shadow flavour (intersect.h:460-467,:476-483,:490-497): t = last tested, return on t < bound */
-template <bool TRI_ONLY, bool COUNT>
+template <int TRI_ONLY, bool COUNT>
 CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay& ray, float bound, float t, unsigned* prims)
 {
     for (int i = first; i < last; i++) {
@@ -1328,7 +1328,7 @@ CRT_DEV void grid_step(GridWalk* w)
     else { w->tz += w->dtz; w->iz += w->sz; }
 }
 
-template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+template <int TRI_ONLY, bool COUNT, bool SHADOW>
 __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_grid(DevScene sc, LaunchArgs la)
 #ifndef CRT_GRID_REFILL_MIN
 #define CRT_GRID_REFILL_MIN 16
 #endif
-template <bool TRI_ONLY, bool COUNT, bool SHADOW>
+template <int TRI_ONLY, bool COUNT, bool SHADOW>
 __global__ __launch_bounds__(CRT_BLOCK) void k_grid_refill(DevScene sc, LaunchArgs la)
 {
     resolve_count(la);
