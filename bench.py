@@ -315,6 +315,8 @@ def main():
                          "the same kernel, so per-kernel profile averages would mix the two trees)")
     ap.add_argument("--no-other-accels", action="store_true", help="skip the binary-BVH / uniform-grid figures of the default line")
     ap.add_argument("--no-render", action="store_true", help="skip the samples/sec/pixel leg (the wavefront path tracer)")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the legs that enqueue the steps alternately on two streams (profiling "
+                    "runs: overlapped launches of one kernel stretch each other, so per-kernel averages would not be the headline launch's)")
     ap.add_argument("--no-strong-projection", action="store_true", help="N = 1: skip the leg that traces the 8 shares of the batch one by one")
     ap.add_argument("--render-spp", type=int, default=32, help="samples per pixel per GPU timed in the render leg")
     ap.add_argument("--render-cpu-spp", type=int, default=48, help="samples per pixel of the render leg's 256x144 cpu_baseline image")
@@ -530,9 +532,10 @@ def main():
     # the same steps enqueued alternately on two streams (both ways of sharing the work)
     two = {}
     p_steps = max(4, min(args.steps, 10))
-    p_el = timed2(step_weak2, p_steps, 2)
-    two["weak"] = {"value": round(float(n) * world * p_steps / p_el / 1e6, 3), "unit": "Mrays/s", "steps": p_steps, "ms_per_step": round(p_el / p_steps * 1e3, 4)}
-    if world > 1:
+    if not args.no_two_streams:
+        p_el = timed2(step_weak2, p_steps, 2)
+        two["weak"] = {"value": round(float(n) * world * p_steps / p_el / 1e6, 3), "unit": "Mrays/s", "steps": p_steps, "ms_per_step": round(p_el / p_steps * 1e3, 4)}
+    if world > 1 and not args.no_two_streams:
         p_el = timed2(step_strong2, p_steps, 2)
         two["strong"] = {"value": round(float(n) * p_steps / p_el / 1e6, 3), "unit": "Mrays/s", "steps": p_steps, "ms_per_step": round(p_el / p_steps * 1e3, 4)}
     step_weak()                                        # leave d_hits holding this rank's own batch for the checks below
@@ -594,6 +597,21 @@ def main():
             for k_ in ("active_lane_fraction", "valu_issue_utilisation", "waves_per_simd"):
                 if tr.get(k_) is not None:
                     rf[k_] = tr[k_]
+            rf["frac_is"] = ("fabric-side bytes (what leaves the L2s: 2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included -- rocprofv3 on "
+                             "gfx950 offers no counter behind the Infinity Cache) / kernel time / HBM peak: an upper bound of the HBM fraction")
+            if tr.get("ea_read_latency_clk") is not None:
+                # What binds, from the counters of the same passes: the reads that leave the L2s take `ea_read_latency_clk` on average and
+                # the L2 channels are (almost) never out of DRAM credits, i.e. the memory side is not pushing back; the traffic is the
+                # reads in flight x 128 B / that latency (Little's law).  The walk is a chain of dependent fetch -> test -> decide steps
+                # whose concurrency (5 waves per SIMD, one fetch group per lane and iteration) fixes that number: "latency", priced
+                # against the HBM peak because the contract's roofline classes are hbm | mfma and this path has no contraction.
+                lat, infl, stall = tr["ea_read_latency_clk"], tr.get("ea_reads_in_flight"), tr.get("dram_credit_stall_fraction")
+                rf["bound_evidence"] = {"ea_read_latency_l2_clk": lat, "ea_reads_in_flight": infl, "dram_credit_stall_fraction": stall,
+                                        "wave_cycles_waiting": tr.get("wave_cycles_waiting"),
+                                        "valu_issue_utilisation": tr.get("valu_issue_utilisation")}
+                if stall is not None and stall < 0.02:
+                    rf["bound"] = "latency"
+                    rf["roofline_class"] = "hbm"
         return rf
 
     accel_name = {"bvh4": "QBVH", "bvh": "binary BVH", "grid": "uniform grid"}[args.accel]
@@ -623,11 +641,12 @@ def main():
     }
     if other:
         out[other["scaling"] + "_scaling"] = other
-    out["two_streams"] = dict(two, what="the same steps enqueued alternately on two HIP streams: consecutive launches overlap (the drain "
-                                       "tail of one beside the start of the next); not the headline, whose steps run on one stream")
+    if two:
+        out["two_streams"] = dict(two, what="the same steps enqueued alternately on two HIP streams: consecutive launches overlap (the drain "
+                                           "tail of one beside the start of the next); not the headline, whose steps run on one stream")
 
     progress("headline leg done")
-    if world == 1 and args.accel == "bvh4" and not shadow and not args.no_strong_projection:
+    if world == 1 and args.accel == "bvh4" and not shadow and not args.no_strong_projection and two:
         # What one GPU can say about strong scaling (ONE batch cut into K shares, Mrays/s(K) = n / max_k time_k): each of the
         # K = 8 shares of THIS batch traced on its own, as rank k of 8 would (crt_intersect_batch_dev_slice: the whole batch binned, a run
         # of whole cells walked), wall-clock with the same barriers as the headline.  The shares must tile the batch: every record of

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
+src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r03")
 path = os.path.join(ROOT, "profiles", "traffic.json")
 db = json.load(open(path)) if os.path.exists(path) else {}
 for d in sorted(os.listdir(src)):
@@ -22,7 +22,7 @@ for d in sorted(os.listdir(src)):
         continue
     builder, mode = d.rsplit("_", 1)
     line = json.loads(open(os.path.join(full, "bench_line.json")).read())
-    want = "k_bvh4_shadow<true, false" if mode == "shadow" else "k_bvh4_closest_tri<false"
+    want = "k_bvh4_shadow<true, false" if mode == "shadow" else "k_bvh4_closest_tri<false, false>"    # the plain walk, not the tail-splitting instance of small launches
     vals, cur = {}, None
     for ln in open(os.path.join(full, "summary.txt")):
         if ln.startswith("kernel:"):
@@ -58,6 +58,17 @@ for d in sorted(os.listdir(src)):
         e["valu_issue_utilisation"] = round(4.0 * vals["SQ_ACTIVE_INST_VALU"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4)
     if "SQ_WAVES" in vals:
         e["waves_per_simd"] = round(vals["SQ_WAVES"] / 1024.0, 2)
+    if vals.get("TCC_EA0_RDREQ_LEVEL_sum") and vals.get("TCC_EA0_RDREQ_sum"):
+        # rocprofv3 --list-avail: "average read latency = EA_RDREQ_LEVEL / EA_RDREQ", in L2 clocks, of the reads that leave the L2s
+        e["ea_read_latency_clk"] = round(vals["TCC_EA0_RDREQ_LEVEL_sum"] / vals["TCC_EA0_RDREQ_sum"], 1)
+        if vals.get("GRBM_GUI_ACTIVE"):
+            # reads in flight past the L2s, averaged over the launch (Little's law: LEVEL summed over cycles / cycles of one XCD)
+            e["ea_reads_in_flight"] = round(vals["TCC_EA0_RDREQ_LEVEL_sum"] / (vals["GRBM_GUI_ACTIVE"] / 8.0), 1)
+            if vals.get("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum") is not None:
+                # cycles (summed over the 128 L2 channels) in which a channel's read interface was out of DRAM credits
+                e["dram_credit_stall_fraction"] = round(vals["TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"] / (128.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    if vals.get("SQ_WAIT_ANY") and vals.get("SQ_WAVE_CYCLES"):
+        e["wave_cycles_waiting"] = round(vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], 3)
     db[key] = e
     shutil.copy(os.path.join(full, "summary.txt"), os.path.join(ROOT, e["source"]))
     print(key, json.dumps(e))

@@ -12,6 +12,7 @@ PASSES=(
  "FETCH_SIZE"
  "WRITE_SIZE GRBM_GUI_ACTIVE"
  "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
+ "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum"
 )
 i=0
 for p in "${PASSES[@]}"; do

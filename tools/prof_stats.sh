@@ -15,7 +15,7 @@ run() {  # name, bench args...
   echo "$name done"
 }
 run full
-run walk_with_reference_tree --no-render --no-other-accels
-run walk --no-render --no-reference-tree --no-other-accels   # the headline launches alone: this average is the one roofline.kernel_ms must match
-run bvh --no-render --accel bvh
-run grid --no-render --accel grid --workload courtyard-1M
+run walk_with_reference_tree --no-render --no-other-accels --no-two-streams --no-strong-projection
+run walk --no-render --no-reference-tree --no-other-accels --no-two-streams --no-strong-projection   # the headline launches alone: this average is the one roofline.kernel_ms must match
+run bvh --no-render --accel bvh --no-two-streams
+run grid --no-render --accel grid --workload courtyard-1M --no-two-streams

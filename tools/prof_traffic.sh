@@ -17,6 +17,7 @@ PASSES=(
  "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
  "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
  "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY"
+ "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum"
 )
 for b in $BUILDERS; do
  for m in $MODES; do
@@ -25,7 +26,7 @@ for b in $BUILDERS; do
   i=0
   for p in "${PASSES[@]}"; do
    i=$((i+1))
-   timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d $D/pass$i -- python3 $R/bench.py --no-cpu-baseline --no-reference-tree --no-render --no-other-accels --steps 5 --warmup 1 --builder $b --mode $m > $D/pass$i.log 2>&1 || { echo "$b $m pass $i failed"; tail -5 $D/pass$i.log; exit 1; }
+   timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d $D/pass$i -- python3 $R/bench.py --no-cpu-baseline --no-reference-tree --no-render --no-other-accels --no-strong-projection --no-two-streams --steps 5 --warmup 1 --builder $b --mode $m > $D/pass$i.log 2>&1 || { echo "$b $m pass $i failed"; tail -5 $D/pass$i.log; exit 1; }
    echo "$b $m pass $i done"
   done
   python3 $R/tools/pmc_summary.py $D > $D/summary.txt
