@@ -28,9 +28,10 @@ for d in sorted(os.listdir(src)):
         if ln.startswith("kernel:"):
             cur = ln.split("kernel:", 1)[1].strip()
         else:
-            m = re.match(r"\s+(\S+)\s+dispatches=(\d+) mean=(\S+)", ln)
+            m = re.match(r"\s+(\S+)\s+dispatches=(\d+) mean=(\S+) min=(\S+)", ln)
             if m and cur and want in cur:
-                vals[m.group(1)] = float(m.group(3))
+                # SQ_WAVES: the smallest dispatch (a counter pass occasionally tallies one dispatch twice over); everything else: the mean
+                vals[m.group(1)] = float(m.group(4) if m.group(1) == "SQ_WAVES" else m.group(3))
     if "FETCH_SIZE" not in vals:
         print("skip", d, "(kernel %s not found)" % want)
         continue
