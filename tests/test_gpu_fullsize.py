@@ -273,3 +273,50 @@ def test_mesh_with_lights_and_spheres_takes_the_pruned_path(accel):
     wt, wocc = o.shadow(rays[:m], ld[:m], nthreads=min(os.cpu_count() or 1, 16))
     assert (st_p[:m] != wt).sum() <= 4 and (occ_p[:m] != wocc).sum() <= 4
     sc.close()
+
+
+@pytest.mark.parametrize("reserve", [False, True])
+def test_batches_larger_than_the_presized_ray_order(reserve):
+    """A batch above 2^24 rays: the ray-order buffers of the binning step are created for 2^24 and either grow inside the first such
+    launch (a stream synchronise, hipFree, hipMalloc) or were sized ahead with crt_scene_reserve_rays.  Either way every record equals
+    the one the same ray gets in a batch of ordinary size (rays are independent), on every accelerator's binned path, closest hit
+    and any hit, and the oracle agrees on a sample."""
+    import torch
+    import bench
+    si = scenes.courtyard(4, 64, 128, seed=5)
+    n = (1 << 24) + 12345
+    dev = torch.device("cuda", 0)
+    for accel in (api.ACCEL_BVH4, api.ACCEL_GRID):
+        built = api.BuiltScene(si, accel, sah=(accel == api.ACCEL_BVH4))
+        sc = api.Scene(built, 0)
+        if reserve:
+            sc.reserve_rays(n)
+        d_rays = bench.gen_incoherent_rays(sc, si, 1 << 22, 0xC0FFEE, dev).repeat(5, 1)[:n].contiguous()
+        d_rays[1 << 22:, :3] += 1.0e-3 * torch.randn((n - (1 << 22), 3), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        d_hits = torch.empty((n, 5), dtype=torch.int32, device=dev)
+        sc.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), None)
+        torch.cuda.synchronize()
+        parts = torch.empty((n, 5), dtype=torch.int32, device=dev)
+        for lo in range(0, n, 1 << 23):
+            m = min(1 << 23, n - lo)
+            sc.intersect_dev(d_rays.data_ptr() + lo * 24, m, parts.data_ptr() + lo * 20, None)
+        torch.cuda.synchronize()
+        assert bool((parts == d_hits).all().item())
+        ld = torch.full((n,), 0.35, dtype=torch.float32, device=dev)
+        t_a = torch.empty(n, dtype=torch.float32, device=dev)
+        occ_a = torch.empty(n, dtype=torch.uint8, device=dev)
+        t_b, occ_b = torch.empty_like(t_a), torch.empty_like(occ_a)
+        sc.shadow_dev(d_rays.data_ptr(), ld.data_ptr(), n, t_a.data_ptr(), occ_a.data_ptr(), None)
+        for lo in range(0, n, 1 << 23):
+            m = min(1 << 23, n - lo)
+            sc.shadow_dev(d_rays.data_ptr() + lo * 24, ld.data_ptr() + lo * 4, m, t_b.data_ptr() + lo * 4, occ_b.data_ptr() + lo, None)
+        torch.cuda.synchronize()
+        assert bool((t_a.view(torch.int32) == t_b.view(torch.int32)).all().item()) and bool((occ_a == occ_b).all().item())
+        m = 1 << 16
+        o = ol.OracleScene(si, accel, built=built)
+        tail = d_rays[n - m:].cpu().numpy()
+        ref = o.intersect(tail, nthreads=min(os.cpu_count() or 1, 16))
+        assert ol.same_bits(d_hits[n - m:].cpu().numpy().view(api.HIT_DTYPE).reshape(-1), ref)
+        o.close()
+        sc.close()
+        built.close()
