@@ -342,6 +342,13 @@ def main():
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (pass --gpus N under a launcher with N ranks)" % (world, args.gpus))
     if args.dry_backend:
         return dry_run(args, rank, world)
+    if world > 1 and "CRT_BUILD_THREADS" not in os.environ:
+        # under a launcher of its own (torchrun) nobody has divided the host cores among the ranks: every rank builds its scene
+        # replicas with its share of them (spawn_ranks sets the same variable for the ranks it starts)
+        cores = os.cpu_count() or 1
+        if os.environ.get("OMP_NUM_THREADS"):
+            cores = min(cores, int(os.environ["OMP_NUM_THREADS"]))
+        os.environ["CRT_BUILD_THREADS"] = str(max(1, cores // int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     if args.builder is None:
         args.builder = "sah" if args.accel == "bvh4" else "reference"
     if args.builder == "sah" and args.accel != "bvh4":
