@@ -200,6 +200,15 @@ def src_hash():
     return h.hexdigest()[:12]
 
 
+_OUT_FD = 1
+
+
+def emit(line):
+    """the one JSON line, to the descriptor that was stdout when main() started"""
+    sys.stdout.flush()
+    os.write(_OUT_FD, (line + "\n").encode())
+
+
 def spawn_ranks(n_gpus, argv, poll_s=0.2, grace_s=5.0):
     """--gpus N without a launcher: start N rank processes of this script (fresh interpreters: this process has
     not imported torch or touched HIP and never will), relay rank 0's output, and SUPERVISE them: the children are
@@ -284,10 +293,10 @@ def dry_run(args, rank, world):
     buf = torch.full((4,), float(rank + 1))
     buf, spp = shard.combine_radiance(buf, 3)
     if rank == 0:
-        print(json.dumps({"metric": "dry run: launch plumbing only, nothing traced", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
+        emit(json.dumps({"metric": "dry run: launch plumbing only, nothing traced", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
                           "higher_is_better": True, "scaling": args.scaling, "dry": True, "backend": args.dry_backend,
-                          "slices": sorted(slices), "combined_radiance": buf.tolist(), "combined_spp": spp}), flush=True)
+                          "slices": sorted(slices), "combined_radiance": buf.tolist(), "combined_spp": spp}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -340,6 +349,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (pass --gpus N under a launcher with N ranks)" % (world, args.gpus))
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever a library prints there on its own (gloo announces its
+    # connections on stdout, from C) goes to stderr instead, and the line is written to the descriptor stdout had
+    global _OUT_FD
+    sys.stdout.flush()
+    _OUT_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.dry_backend:
         return dry_run(args, rank, world)
     if world > 1 and "CRT_BUILD_THREADS" not in os.environ:
@@ -835,7 +850,7 @@ def main():
                                "one_thread_mrays": round(m1 / cpu1_s / 1e6, 4), "one_thread_O0_mrays": o0_mrays,
                                "gpu_bit_identical_on_sample": same}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     sc.close()
     if world > 1:
         dist.destroy_process_group()

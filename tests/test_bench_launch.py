@@ -30,6 +30,7 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = json_lines(p)
     assert len(lines) == 1
+    assert len(p.stdout.strip().splitlines()) == 1          # nothing else on stdout: gloo's own announcements go to stderr
     j = lines[0]
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["dry"] is True and j["scaling"] == "strong"
     # two ranks answered, and their slices tile the batch: contiguous, disjoint, sizes differing by at most one
