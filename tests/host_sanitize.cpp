@@ -116,9 +116,36 @@ static int scene_file_checks()
     const char* words[] = { "MATERIAL", "MATTE", "MIRROR", "TRANSPARENT", "EMISSIVE", "PLASTIC", "GLASS", "METAL", "NAME", "a", "COLOR", "RED", "0.5", "SIGMA", "END",
         "END_MATERIALS", "OBJECT", "SPHERE", "PLANE", "RECTANGLE", "TRIANGLE", "BOX", "TORUS", "OPENCYLINDER", "SOLIDCYLINDER", "DISK", "MESH", "RADIUS", "CENTER",
         "POINT", "NORMAL", "WIDTH", "HEIGHT", "LENGTH", "V0", "V1", "V2", "LOCATION", "SCALE", "ORIENTATION", "NORMAL_TYPE", "OPEN", "bogus", "FILE_NAME", "/nonexistent.obj",
-        "SMOOTH", "yes", "ENV_LIGHT", "TYPE", "CONSTANT", "TEXTURE", "x.exr", "INTENSITY", "-1", "1e39", "nan", "#", "#x", "\n", "\t", "\r\n", "KD", "KS", "ROUGHNESS", "GOLD",
+        "SMOOTH", "yes", "ENV_LIGHT", "TYPE", "CONSTANT", "TEXTURE", "x.exr", "KD_TEXTURE", "NORMAL_MAP", "/tmp/crt_sanitize_t.ppm", "/tmp/crt_sanitize_bad.ppm",
+        "crt_sanitize_t.ppm", "INTENSITY", "-1", "1e39", "nan", "#", "#x", "\n", "\t", "\r\n", "KD", "KS", "ROUGHNESS", "GOLD",
         "WINDOW_WIDTH", "FOV", "CAMERA_POS", "LOOK_POINT", "0", "0 0 0", "1 2", "" };
     const int nw = (int)(sizeof words / sizeof words[0]);
+    /* texture files the soup can name: a good 3 x 2 PPM and hostile ones for the reader itself (PPM_read, imagefile.h:59-83) */
+    {
+        unsigned char px[18]; for (int i = 0; i < 18; i++) px[i] = (unsigned char)(i * 13);
+        if (crt_ppm_write("/tmp/crt_sanitize_t.ppm", px, 3, 2) != CRT_OK) { printf("ppm write\n"); return 1; }
+        crt_texture t; memset(&t, 0, sizeof t);
+        if (crt_texture_load_ppm("/tmp/crt_sanitize_t.ppm", &t) != CRT_OK || t.width != 3 || t.height != 2 || t.comp != 3 || t.is_float ||
+            memcmp(t.data, px, 18)) { printf("ppm read back\n"); return 1; }
+        crt_texture_free(&t);
+        const char* bad[] = { "", "P6", "P6\n", "P6\n3", "P6\n3 2\n", "P6\n3 2\n255\n", "P6\n3 2\n255\nshort", "P6\n-3 2\n255\nxxxxxxxxxxxxxxxxxx",
+                              "P6\n100000 100000\n255\nx", "P6\n2147483647 2147483647\n255\nx", "P6\n0 0\n255\n", "P6\n3 2\n65535\nxxxxxxxxxxxxxxxxxx",
+                              "P5\n3 2\n255\nxxxxxx", "P6\n3 x\n255\nxxxxxxxxxxxxxxxxxx", "P6 3 2 255 xxxxxxxxxxxxxxxxxx" };
+        for (const char* b : bad) {
+            if (write_file("/tmp/crt_sanitize_bad.ppm", b)) return 1;
+            crt_texture u; memset(&u, 0, sizeof u);
+            const int rc = crt_texture_load_ppm("/tmp/crt_sanitize_bad.ppm", &u);
+            if (rc == CRT_OK) {                              // whatever it accepts must be consistent and readable to its end
+                if (u.width <= 0 || u.height <= 0 || u.comp != 3 || !u.data) { printf("ppm accepted inconsistently: '%s'\n", b); return 1; }
+                unsigned sum = 0; for (long long i = 0; i < (long long)u.width * u.height * 3; i++) sum += ((const unsigned char*)u.data)[i];
+                (void)sum;
+                crt_texture_free(&u);
+            } else if (u.data) { printf("ppm: data set on failure\n"); return 1; }
+        }
+        if (crt_texture_load_ppm(0, &t) != CRT_E_INVALID || crt_texture_load_ppm("/tmp/crt_sanitize_t.ppm", 0) != CRT_E_INVALID) { printf("ppm argument checks\n"); return 1; }
+        crt_texture_free(0);
+        if (write_file("/tmp/crt_sanitize_bad.ppm", "P6\n3 2\n255\nshort")) return 1;     // what the soup's second name points at
+    }
     for (int round = 0; round < 400; round++) {
         std::string text;
         const int len = 1 + rand() % 120;
@@ -131,6 +158,15 @@ static int scene_file_checks()
         if (v->input.num_obj < 0 || v->num_materials < 0) { printf("scene file counts\n"); return 1; }
         for (int i = 0; i < v->input.num_obj; i++)
             if (v->obj_material[i] < -1 || v->obj_material[i] >= v->num_materials) { printf("scene file material index\n"); return 1; }
+        if (v->num_textures < 0 || v->env_map_tex < -1 || v->env_map_tex >= v->num_textures) { printf("scene file texture counts\n"); return 1; }
+        for (int m = 0; m < v->num_materials; m++)
+            if (v->material_diffuse_tex[m] < -1 || v->material_diffuse_tex[m] >= v->num_textures ||
+                v->material_normal_tex[m] < -1 || v->material_normal_tex[m] >= v->num_textures) { printf("scene file texture index\n"); return 1; }
+        for (int t = 0; t < v->num_textures; t++) {
+            if (!v->texture_names[t]) { printf("scene file texture name\n"); return 1; }
+            const crt_texture& tx = v->textures[t];
+            if (tx.data) { unsigned sum = 0; for (long long i = 0; i < (long long)tx.width * tx.height * tx.comp; i++) sum += ((const unsigned char*)tx.data)[i]; (void)sum; }
+        }
         char what[64]; snprintf(what, sizeof what, "scene file round %d", round);
         if (v->input.num_obj > 0 && build_all(v->input, what, true)) return 1;     // NaN / zero-extent geometry: the grid may refuse
         crt_scene_file_free(sf);
@@ -141,7 +177,7 @@ static int scene_file_checks()
     crt_scene_file_free(0);
     float r = 0;
     if (crt_env_world_radius(0, &r) != CRT_E_INVALID) { printf("world radius null check\n"); return 1; }
-    remove(path);
+    remove(path); remove("/tmp/crt_sanitize_t.ppm"); remove("/tmp/crt_sanitize_bad.ppm");
     return 0;
 }
 
