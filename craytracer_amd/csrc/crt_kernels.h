@@ -367,6 +367,9 @@ CRT_DEV float linear_shadow(const DevScene& sc, int first, int last, const DRay&
 #ifndef CRT_PROBE_NO_FALLBACK
 #define CRT_PROBE_NO_FALLBACK 0   /* register-pressure probe only: results are wrong for rays that are not `clean` */
 #endif
+#ifndef CRT_PENDING_LEAF_SHADOW
+#define CRT_PENDING_LEAF_SHADOW 1
+#endif
 #ifndef CRT_DIAG
 #define CRT_DIAG 0                /* diagnostic build: per-iteration lane statistics of the closest-hit walk into counters[8..] */
 #endif
@@ -941,6 +944,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
 
     bool alive = false;
     unsigned ri = 0, cur = 0;
+    unsigned pl = 0;              /* CRT_PENDING_LEAF_SHADOW: leaf word whose objects are being tested (count field 0 = none) */
     DRay ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = ray.dy = ray.dz = 1.0f;
     float ia = 1.0f, ib = 1.0f, ic = 1.0f, ld = 0.0f, result = CRT_TMAX;
     bool px = true, walking = false;
@@ -968,6 +972,7 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
                 result = CRT_TMAX;
                 st.sp = 0;
                 cur = sc.root_word;
+                pl = 0u;
                 walking = sc.n_accel > 0;
                 alive = true;
             }
@@ -975,8 +980,10 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
         }
         if (__ballot(alive) == 0ull) break;
         if (alive) {
+            constexpr bool PEND = TRI_ONLY && COMPRESSED && CRT_PENDING_LEAF_SHADOW;
+            bool need_pop = true, found = false;
             if (walking) {
-                bool need_pop = true;
+                if (PEND && (cur & CRT_LEAF_BIT)) need_pop = false;       /* a leaf that has been waiting for `pl` to become free */
                 if (!(cur & CRT_LEAF_BIT)) {
                     const int ax2 = (int)((cur >> 28) & 3u);
                     if (COUNT) c_nodes++;
@@ -1029,11 +1036,17 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
                     if (s1v) st.push(s1w);
                     if (s0v) { cur = s0w; need_pop = false; }
                 }
+                if (PEND) {
+                    /* as in the closest-hit walk: the leaf being tested sits in a register of its own (`pl`) and gives one object
+                     * per iteration while the walk goes on.  Leaves enter `pl` one at a time, in walk order (a second one waits in
+                     * `cur`), so objects are tested in the reference's order and the first t < light_dist found is the reference's. */
+                    if (!need_pop && (cur & CRT_LEAF_BIT) && ((pl >> 28) & 7u) == 0u) { pl = cur; need_pop = true; }
+                } else
 #if CRT_FUSE_LEAF_SHADOW
                 if (cur & CRT_LEAF_BIT) {
                     need_pop = true;
 #else
-                else {
+                if (!!(cur & CRT_LEAF_BIT) == need_pop) {                  /* (a leaf that the node step has not just entered) */
 #endif
                     /* one object of the leaf per step, in array order (bvh4.h:464-472) */
                     const int count = (int)((cur >> 28) & 7u);
@@ -1046,12 +1059,23 @@ __global__ __launch_bounds__(CRT_BLOCK) CRT_WALK_WAVES void k_bvh4_shadow(DevSce
                     }
                     if (walking && count > 1) { cur = CRT_LEAF_BIT | ((unsigned)(count - 1) << 28) | (unsigned)(first + 1); need_pop = false; }
                 }
-                if (need_pop) {
-                    if (st.sp > 0) cur = st.pop();
-                    else walking = false;
+            }
+            if (PEND) {
+                const unsigned pcount = (pl >> 28) & 7u;
+                if (pcount > 0u) {
+                    const unsigned first = pl & 0x0FFFFFFFu;
+                    DHit h;
+                    const float t = dev_object<TRI_ONLY>(sc, (int)first, ray, true, &h);
+                    if (COUNT) c_prims++;
+                    pl = pcount > 1u ? (CRT_LEAF_BIT | ((pcount - 1u) << 28) | (first + 1u)) : 0u;
+                    if (t < ld) { result = t; found = true; walking = false; pl = 0u; }
                 }
             }
-            if (!walking) {
+            if (walking && need_pop) {
+                if (st.sp > 0) cur = st.pop();
+                else walking = false;
+            }
+            if (!walking && (!PEND || found || ((pl >> 28) & 7u) == 0u)) {
                 if (result >= ld)                                                      /* intersect.h:474 */
                     result = linear_shadow<TRI_ONLY, COUNT>(sc, 0, sc.nng, ray, ld, result, &c_prims);
                 if (la.t_out) la.t_out[ri] = result;
