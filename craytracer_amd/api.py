@@ -157,7 +157,7 @@ EXPORTS = [
     "crt_scene_file_load", "crt_scene_file_get", "crt_scene_file_free", "crt_env_world_radius",
     "crt_build_scene", "crt_build_scene_ex", "crt_built_scene_desc", "crt_built_scene_destroy",
     "crt_device_count", "crt_scene_create", "crt_scene_destroy",
-    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning", "crt_scene_set_node_compression",
+    "crt_scene_set_traverse_mode", "crt_scene_get_traverse_mode", "crt_scene_set_ray_binning", "crt_scene_get_ray_binning", "crt_scene_set_node_compression",
     "crt_host_grid_distance_field", "crt_host_qbvh_node_order", "crt_host_bvh2_wide_records",
     "crt_scene_set_wide_nodes", "crt_host_qbvh_wide8_records",
     "crt_host_alloc", "crt_host_free",
@@ -205,6 +205,7 @@ def lib():
     L.crt_scene_set_traverse_mode.argtypes = [vp, C.c_int]
     L.crt_scene_get_traverse_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.crt_scene_set_ray_binning.argtypes = [vp, C.c_int]
+    L.crt_scene_get_ray_binning.argtypes = [vp, C.POINTER(C.c_int)]
     L.crt_scene_set_node_compression.argtypes = [vp, C.c_int]
     L.crt_host_grid_distance_field.argtypes = [C.POINTER(CrtSceneDesc), vp]
     L.crt_host_qbvh_node_order.argtypes = [C.POINTER(CrtSceneDesc), C.c_int, vp, C.POINTER(C.c_int32)]

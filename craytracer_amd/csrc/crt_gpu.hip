@@ -1188,6 +1188,13 @@ int crt_scene_set_ray_binning(crt_scene* s, int on)
     s->binning = on != 0;
     return CRT_OK;
 }
+int crt_scene_get_ray_binning(crt_scene* s, int* on)
+{
+    if (!s || !on) return CRT_E_INVALID;
+    std::lock_guard<std::mutex> lock(s->mu);
+    *on = s->binning ? 1 : 0;
+    return CRT_OK;
+}
 int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
 {
     if (!s || !resolved) return CRT_E_INVALID;

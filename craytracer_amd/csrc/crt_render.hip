@@ -787,6 +787,8 @@ struct crt_renderer {
     crt_render_stats stats;
     hipStream_t stream;
     hipStream_t stream2; bool stream2_valid;          /* the shadow query and the accumulation of a bounce run here, beside the next bounce's extend query */
+    int nobin_s_upto;
+    int nobin_e_upto;                                 /* queries that go out unbinned: see crt_renderer_create */
     std::vector<hipEvent_t> ev_sync;                  /* 2 per bounce launched in a pass: shade done (stream), accumulate done (stream2) */
     std::vector<void*> allocs;
     /* the host follows the device two bounces behind: the queue sizes of each bounce land here (page-locked) */
@@ -993,6 +995,14 @@ int crt_renderer_create(crt_scene* scene, const crt_render_desc* d, const crt_ca
     if (!r) return CRT_E_NOMEM;
     r->scene = scene; r->device = device; r->samples = 0; r->stream = 0; r->stream2 = 0; r->stream2_valid = false;
     r->h_counts = 0; r->counts_words = 0;
+    /* The renderer's queries are not binned (round 3).  Its ray queues are in path order -- pixel by pixel, sample by sample,
+     * compacted as paths die -- which keeps neighbouring rays near each other for as long as the surfaces do; sorting them once
+     * more by the cell of their origin costs 7 % of the kernel time and was measured to lose against leaving them alone at
+     * every bounce (4K courtyard, depth 5: 31.6 samples/s/pixel all binned, 32.1 camera rays and their shadow rays left alone,
+     * 33.5 nothing binned).  A/B knobs: CRT_RENDER_NOBIN_EXTEND_UPTO / CRT_RENDER_NOBIN_SHADOW_UPTO = last bounce whose extend /
+     * shadow query goes out unbinned (-1: every query is binned, as crt_intersect_batch_dev does for a caller's batch). */
+    { const char* e = getenv("CRT_RENDER_NOBIN_EXTEND_UPTO"); r->nobin_e_upto = e ? atoi(e) : (1 << 30); }
+    { const char* e = getenv("CRT_RENDER_NOBIN_SHADOW_UPTO"); r->nobin_s_upto = e ? atoi(e) : (1 << 30); }
     memset(&r->stats, 0, sizeof r->stats);
     memset(&r->rd, 0, sizeof r->rd);
     DevGuard g(device);
@@ -1178,7 +1188,12 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
             hipEvent_t* ev = &r->ev_time[4 * (size_t)bounce];
             hipEvent_t* sy = &r->ev_sync[2 * (size_t)bounce];
             if (hipEventRecord(ev[0], st) != hipSuccess) return CRT_E_HIP;
+            /* not binned (see crt_renderer_create): the queue is in path order */
+            int bin_was = 1;
+            const bool nobin0 = bounce <= r->nobin_e_upto;
+            if (nobin0) { (void)crt_scene_get_ray_binning(r->scene, &bin_was); if (bin_was) (void)crt_scene_set_ray_binning(r->scene, 0); }
             int rc = crt_intersect_batch_dev_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, n_bound, rd.hits, st);
+            if (nobin0 && bin_was) (void)crt_scene_set_ray_binning(r->scene, 1);
             if (rc != CRT_OK) return rc;
             if (hipEventRecord(ev[1], st) != hipSuccess) return CRT_E_HIP;
             if (bounce > 0 && hipStreamWaitEvent(st, r->ev_sync[2 * (size_t)(bounce - 1) + 1], 0) != hipSuccess) return CRT_E_HIP;   /* accumulate(bounce - 1) */
@@ -1188,7 +1203,10 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
             if (hipEventRecord(sy[0], st) != hipSuccess) return CRT_E_HIP;
             if (hipStreamWaitEvent(st2, sy[0], 0) != hipSuccess) return CRT_E_HIP;
             if (hipEventRecord(ev[2], st2) != hipSuccess) return CRT_E_HIP;
+            const bool nobin_s = bounce <= r->nobin_s_upto;
+            if (nobin_s) { (void)crt_scene_get_ray_binning(r->scene, &bin_was); if (bin_was) (void)crt_scene_set_ray_binning(r->scene, 0); }
             rc = crt_shadow_batch_dev_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, n_bound, 0, rd.socc, st2);
+            if (nobin_s && bin_was) (void)crt_scene_set_ray_binning(r->scene, 1);
             if (rc != CRT_OK) return rc;
             if (hipEventRecord(ev[3], st2) != hipSuccess) return CRT_E_HIP;
             hipLaunchKernelGGL(k_pt_accumulate, dim3((n_bound + 255) / 256), dim3(256), 0, st2, rd, n_bound, bounce);
