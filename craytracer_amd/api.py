@@ -805,6 +805,11 @@ class Scene:
     def set_ray_binning(self, on=True):
         _check(lib().crt_scene_set_ray_binning(self._h, 1 if on else 0), "crt_scene_set_ray_binning")
 
+    def ray_binning(self):
+        on = C.c_int()
+        _check(lib().crt_scene_get_ray_binning(self._h, C.byref(on)), "crt_scene_get_ray_binning")
+        return bool(on.value)
+
     def set_wide_nodes(self, on=True):
         """Closest-hit launches walk the 8-wide copy of the QBVH (default) or the 4-wide copies only; same hit records."""
         _check(lib().crt_scene_set_wide_nodes(self._h, 1 if on else 0), "crt_scene_set_wide_nodes")

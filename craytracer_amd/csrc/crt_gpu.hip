@@ -11,6 +11,7 @@
 #include "crt_wide8_host.h"
 #include "crt_binning.h"
 #include "crt_camera.h"
+#include "crt_internal.h"
 
 #include <string.h>
 #include <stdio.h>
@@ -535,8 +536,9 @@ const int CRT_MAX_BLOCKS_PER_CU = CRT_MAX_BLOCKS;
 typedef void (*WalkKernel)(DevScene, LaunchArgs);
 struct LaunchOpts {
     bool use_binning; bool noalloc; int max_blocks; unsigned slice, slice_count;
+    bool no_bin;              /* this launch is not binned whatever the scene's setting (the renderer's queues are in path order) */
     WalkKernel followup;      /* k_bvh8_closest_tri launches: the 4-wide walk that takes the rays the 8-wide one leaves (crt_wide8.h), or null */
-    LaunchOpts(bool bin = false, bool na = false, int mb = CRT_MAX_BLOCKS_PER_CU) : use_binning(bin), noalloc(na), max_blocks(mb), slice(0), slice_count(0), followup(0) {}
+    LaunchOpts(bool bin = false, bool na = false, int mb = CRT_MAX_BLOCKS_PER_CU) : use_binning(bin), noalloc(na), max_blocks(mb), slice(0), slice_count(0), no_bin(false), followup(0) {}
 };
 #define CRT_FB_COUNT_WORD 8        /* words of the 256-byte queue-head line (zeroed before every launch): the fallback list's length, */
 #define CRT_FB_HEAD_WORD  16       /* ... and the queue head of the launch that walks it */
@@ -573,7 +575,7 @@ int launch_locked(crt_scene* s, K kernel, LaunchArgs la, hipStream_t stream, con
     }
     if (per_cu > o.max_blocks * (256 / CRT_BLOCK)) per_cu = o.max_blocks * (256 / CRT_BLOCK);      /* max_blocks counts 256-thread blocks */
     unsigned blocks = (unsigned)(s->num_cus * per_cu);
-    const bool bin = o.use_binning && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
+    const bool bin = o.use_binning && !o.no_bin && s->binning && s->bin_grid_valid && la.n >= CRT_BIN_MIN_RAYS;
     /* a slice of a batch that is not binned is a slice by ray index */
     unsigned walk_n = la.n;
     la.q_first = 0; la.q_range = 0;
@@ -702,11 +704,11 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, LaunchO
     }
 }
 template <bool TRI_ONLY, bool COUNT>
-int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st, unsigned slice = 0, unsigned slice_count = 0)
+int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st, unsigned slice = 0, unsigned slice_count = 0, bool no_bin = false)
 {
     const bool exact = resolved_mode(s) == CRT_TRAVERSE_EXACT;
     LaunchOpts o(true);
-    o.slice = slice; o.slice_count = slice_count;
+    o.slice = slice; o.slice_count = slice_count; o.no_bin = no_bin;
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, o);
                          return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, o);
@@ -1203,7 +1205,7 @@ int crt_scene_get_traverse_mode(const crt_scene* s, int* resolved)
 }
 
 static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit* d_hits, void* stream, bool noalloc, const uint32_t* d_n = 0,
-                         unsigned slice = 0, unsigned slice_count = 0)
+                         unsigned slice = 0, unsigned slice_count = 0, bool no_bin = false)
 {
     if (!s || (n > 0 && (!d_rays || !d_hits))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -1216,7 +1218,7 @@ static int intersect_dev(crt_scene* s, const crt_ray* d_rays, size_t n, crt_hit*
     la.rays = d_rays; la.hits = d_hits; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
     LaunchOpts o(true, noalloc);
-    o.slice = slice; o.slice_count = slice_count;
+    o.slice = slice; o.slice_count = slice_count; o.no_bin = no_bin;
     if (s->tri_only) return s->count ? dispatch_closest<true, true>(s, la, st, o) : dispatch_closest<true, false>(s, la, st, o);
     return s->count ? dispatch_closest<false, true>(s, la, st, o) : dispatch_closest<false, false>(s, la, st, o);
 }
@@ -1268,7 +1270,8 @@ int crt_intersect_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const u
 }
 
 static int shadow_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
-                      float* d_t_out, uint8_t* d_occluded_out, void* stream, const uint32_t* d_n, unsigned slice = 0, unsigned slice_count = 0)
+                      float* d_t_out, uint8_t* d_occluded_out, void* stream, const uint32_t* d_n, unsigned slice = 0, unsigned slice_count = 0,
+                      bool no_bin = false)
 {
     if (!s || (n > 0 && (!d_rays || !d_light_dist))) return CRT_E_INVALID;
     if (n == 0) return CRT_OK;
@@ -1279,8 +1282,8 @@ static int shadow_dev(crt_scene* s, const crt_ray* d_rays, const float* d_light_
     memset(&la, 0, sizeof la);
     la.rays = d_rays; la.light_dist = d_light_dist; la.t_out = d_t_out; la.occ_out = d_occluded_out; la.n = (unsigned)n; la.n_dev = d_n;
     hipStream_t st = (hipStream_t)stream;
-    if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st, slice, slice_count) : dispatch_shadow<true, false>(s, la, st, slice, slice_count);
-    return s->count ? dispatch_shadow<false, true>(s, la, st, slice, slice_count) : dispatch_shadow<false, false>(s, la, st, slice, slice_count);
+    if (s->tri_only) return s->count ? dispatch_shadow<true, true>(s, la, st, slice, slice_count, no_bin) : dispatch_shadow<true, false>(s, la, st, slice, slice_count, no_bin);
+    return s->count ? dispatch_shadow<false, true>(s, la, st, slice, slice_count, no_bin) : dispatch_shadow<false, false>(s, la, st, slice, slice_count, no_bin);
 }
 int crt_shadow_batch_dev_slice(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, size_t n,
                                float* d_t_out, uint8_t* d_occluded_out, uint32_t slice, uint32_t num_slices, void* stream)
@@ -1299,6 +1302,24 @@ int crt_shadow_batch_dev_counted(crt_scene* s, const crt_ray* d_rays, const floa
     if (!d_n) return CRT_E_INVALID;
     return shadow_dev(s, d_rays, d_light_dist, n_max, d_t_out, d_occluded_out, stream, d_n);
 }
+
+} /* extern "C" */
+
+/* Library-internal (crt_internal.h, not exported): the renderer's counted queries with the binning decided per call instead of
+ * through the scene's setting, so that a renderer and another caller of the same scene do not see each other's choice. */
+int crt_internal_intersect_counted(crt_scene* s, const crt_ray* d_rays, const uint32_t* d_n, size_t n_max, crt_hit* d_hits, void* stream, bool binned)
+{
+    if (!d_n) return CRT_E_INVALID;
+    return intersect_dev(s, d_rays, n_max, d_hits, stream, false, d_n, 0, 0, !binned);
+}
+int crt_internal_shadow_counted(crt_scene* s, const crt_ray* d_rays, const float* d_light_dist, const uint32_t* d_n, size_t n_max,
+                                float* d_t_out, uint8_t* d_occluded_out, void* stream, bool binned)
+{
+    if (!d_n) return CRT_E_INVALID;
+    return shadow_dev(s, d_rays, d_light_dist, n_max, d_t_out, d_occluded_out, stream, d_n, 0, 0, !binned);
+}
+
+extern "C" {
 
 /* Host-buffer entry points.  The batch is cut into chunks that alternate between two streams,
  * each doing  H2D(chunk) -> traversal kernel -> D2H(chunk)  in stream order, so the copies of one

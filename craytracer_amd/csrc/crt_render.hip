@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/crt_gpu.h"
+#include "crt_internal.h"
 #include "crt_camera.h"
 #include "crt_libm.h"
 #include "crt_shaderec.h"
@@ -1189,11 +1190,7 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
             hipEvent_t* sy = &r->ev_sync[2 * (size_t)bounce];
             if (hipEventRecord(ev[0], st) != hipSuccess) return CRT_E_HIP;
             /* not binned (see crt_renderer_create): the queue is in path order */
-            int bin_was = 1;
-            const bool nobin0 = bounce <= r->nobin_e_upto;
-            if (nobin0) { (void)crt_scene_get_ray_binning(r->scene, &bin_was); if (bin_was) (void)crt_scene_set_ray_binning(r->scene, 0); }
-            int rc = crt_intersect_batch_dev_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, n_bound, rd.hits, st);
-            if (nobin0 && bin_was) (void)crt_scene_set_ray_binning(r->scene, 1);
+            int rc = crt_internal_intersect_counted(r->scene, rd.rays[cur], rd.counters + 2 * bounce, n_bound, rd.hits, st, bounce > r->nobin_e_upto);
             if (rc != CRT_OK) return rc;
             if (hipEventRecord(ev[1], st) != hipSuccess) return CRT_E_HIP;
             if (bounce > 0 && hipStreamWaitEvent(st, r->ev_sync[2 * (size_t)(bounce - 1) + 1], 0) != hipSuccess) return CRT_E_HIP;   /* accumulate(bounce - 1) */
@@ -1203,10 +1200,7 @@ int crt_renderer_render(crt_renderer* r, uint32_t num_samples)
             if (hipEventRecord(sy[0], st) != hipSuccess) return CRT_E_HIP;
             if (hipStreamWaitEvent(st2, sy[0], 0) != hipSuccess) return CRT_E_HIP;
             if (hipEventRecord(ev[2], st2) != hipSuccess) return CRT_E_HIP;
-            const bool nobin_s = bounce <= r->nobin_s_upto;
-            if (nobin_s) { (void)crt_scene_get_ray_binning(r->scene, &bin_was); if (bin_was) (void)crt_scene_set_ray_binning(r->scene, 0); }
-            rc = crt_shadow_batch_dev_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, n_bound, 0, rd.socc, st2);
-            if (nobin_s && bin_was) (void)crt_scene_set_ray_binning(r->scene, 1);
+            rc = crt_internal_shadow_counted(r->scene, rd.srays, rd.sdist, rd.counters + 2 * (bounce + 1) + 1, n_bound, 0, rd.socc, st2, bounce > r->nobin_s_upto);
             if (rc != CRT_OK) return rc;
             if (hipEventRecord(ev[3], st2) != hipSuccess) return CRT_E_HIP;
             hipLaunchKernelGGL(k_pt_accumulate, dim3((n_bound + 255) / 256), dim3(256), 0, st2, rd, n_bound, bounce);

@@ -219,7 +219,7 @@ void crt_host_free(void* p);
  * origin and pulls rays from the queue in that order (better L2 reuse); every ray is traced
  * exactly as before and its result is written at its own index, so outputs do not change. */
 int  crt_scene_set_ray_binning(crt_scene* s, int on);
-int  crt_scene_get_ray_binning(crt_scene* s, int* on);   /* the current setting (crt_renderer_render switches binning off around its own launches and restores it) */
+int  crt_scene_get_ray_binning(crt_scene* s, int* on);   /* the current setting (crt_renderer_render does not touch it: its own queries are unbinned per launch) */
 
 /* Compressed node copy (experiment switch; see DESIGN.md for its default).  No counterpart in the reference.  For QBVH
  * scenes crt_scene_create also keeps a 64-byte conservative copy of every node (per axis an origin and a scale, per

@@ -229,6 +229,34 @@ def test_sample_ranges_rendered_apart_add_up():
     assert np.allclose(lo + hi, whole, rtol=1e-5, atol=1e-6)
 
 
+def test_the_renderer_leaves_the_scene_s_binning_setting_alone():
+    """The renderer's own queries go out unbinned (their queues are in path order); that is decided per launch, not by
+    switching the scene's setting: the setting reads the same before and after a render, on or off, and a caller's
+    batch through the same scene is binned or not as the caller chose -- with identical hit records either way."""
+    si, desc, pos, look = scenes.courtyard_render(4, 32, 64, max_depth=3, rng_seed=5)
+    cam = api.make_camera(pos, look, focal_pt_dist=0.05)
+    flm = api.make_film(cam, 1.2, 512, 512)              # 2^18 pixels: the queries are large enough to be binned
+    built = api.BuiltScene(si, api.ACCEL_BVH4)
+    scene = api.Scene(built)
+    rays = scenes.random_rays(1 << 18, *scenes.scene_bounds(si), seed=3)
+    images, hits = [], []
+    for on in (True, False):
+        scene.set_ray_binning(on)
+        assert scene.ray_binning() is on
+        r = api.Renderer(scene, desc, cam, flm)
+        r.render(2)
+        assert scene.ray_binning() is on
+        assert scene.last_binning_ms() == 0.0            # this thread's last launch was the renderer's: not binned
+        images.append(r.read()[0])
+        r.close()
+        hits.append(scene.intersect(rays).copy())
+        assert (scene.last_binning_ms() > 0.0) is on     # the caller's batch: as the caller chose
+    scene.close()
+    built.close()
+    assert ol.same_bits(images[0], images[1])
+    assert (hits[0].view(np.uint8) == hits[1].view(np.uint8)).all()
+
+
 def test_depth_zero_is_emission_only():
     si, desc = scenes.cornell29_render(max_depth=0, seed=1)
     cam, flm = scenes.cornell_camera(64, 64)
