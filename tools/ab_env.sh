@@ -8,7 +8,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('[$e]', 'rep$rep', d['value'], 'Mrays/s', 'kernel_ms', r['kernel_ms'], 'chk', d['config']['hits_checksum'], 'nodes', r['algorithmic']['nodes_per_ray'], 'anyhit', d.get('any_hit', {}).get('value'))
+        print('[$e]', 'rep$rep', d['value'], 'Mrays/s', 'kernel_ms', r['kernel_ms'], 'chk', d['config']['hits_checksum'], 'nodes', r['algorithmic']['nodes_per_ray'], 'bin_ms', r['binning_ms'], 'anyhit', d.get('any_hit', {}).get('value'))
 " || exit 1
 done
 done
