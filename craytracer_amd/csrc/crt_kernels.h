@@ -12,6 +12,13 @@
 #pragma once
 #include "crt_device.h"
 
+/* The ray records and the hit records are touched once per launch: they are read and written with the non-temporal hint, so that
+ * 740 MB of them per 2^24 rays pass through the L2s and the Infinity Cache without displacing the tree.  Closest hit 7.98 -> 7.81 ms
+ * (+2 %), any hit unchanged.  The same hint on the ray order, the light distances and the any-hit results measured -1 % on the
+ * any-hit walk, and on the binning kernels' scattered writes 0.32 -> 0.88 ms (they lose their write combining): rays and hits only. */
+#ifndef CRT_NT_IO
+#define CRT_NT_IO 1
+#endif
 #ifndef CRT_BLOCK
 #define CRT_BLOCK      256         /* threads per workgroup of the walk kernels (a multiple of 64 that divides 256) */
 #endif
@@ -132,8 +139,13 @@ struct LaneStack32 {
 
 CRT_DEV DRay load_ray(const crt_ray* rays, unsigned i)
 {
-    const float2* p = reinterpret_cast<const float2*>(rays + i);    /* 24-B records, 8-B aligned */
-    float2 a = p[0], b = p[1], c = p[2];
+    typedef float ld2f __attribute__((ext_vector_type(2)));
+    const ld2f* p = reinterpret_cast<const ld2f*>(rays + i);        /* 24-B records, 8-B aligned */
+#if CRT_NT_IO
+    const ld2f a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1), c = __builtin_nontemporal_load(p + 2);
+#else
+    const ld2f a = p[0], b = p[1], c = p[2];
+#endif
     DRay r; r.ox = a.x; r.oy = a.y; r.oz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
     return r;
 }
@@ -143,7 +155,14 @@ CRT_DEV void store_hit(crt_hit* hits, unsigned i, float t, const DHit& h)
     o.t = t;
     if (t < CRT_TMAX) { o.obj = h.obj; o.part = h.part; o.beta = h.beta; o.gamma = h.gamma; }
     else { o.obj = -1; o.part = -1; o.beta = 0.0f; o.gamma = 0.0f; }
+#if CRT_NT_IO
+    typedef float st4f __attribute__((ext_vector_type(4)));
+    const st4f v = { o.t, __int_as_float(o.obj), __int_as_float(o.part), o.beta };
+    __builtin_nontemporal_store(v, reinterpret_cast<st4f*>(hits + i));          /* 20-B records, 4-B aligned: global_store_dwordx4 takes that */
+    __builtin_nontemporal_store(o.gamma, reinterpret_cast<float*>(hits + i) + 4);
+#else
     hits[i] = o;
+#endif
 }
 
 /* Wave-level fetch of the next 64 queue slots. */
