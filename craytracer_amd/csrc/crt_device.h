@@ -50,6 +50,7 @@ struct DevScene {
     int n_accel;                    /* num_obj - nng */
     int accel;
     const float4* bnodes2w;         /* binary BVH collapsed two levels at a time: 128-byte records of up to four boxes (crt_gpu.hip) */
+    const uint4* bnodes2wc;         /* ... the same records once more as 64-byte conservative records (the QBVH's compressed-node layout), or null */
     unsigned root_word_w;           /* its root in child-word form */
     unsigned root_word;             /* QBVH: axis2(root) << 28 | 0;  BVH: child-word form of the root */
     const float4* bnodes2;          /* BVH: 64-byte inner-node records for k_bvh2 (see crt_kernels.h) */

@@ -93,7 +93,7 @@ struct crt_scene {
                                  walk may take the nearer child first and settle equal t by index (k_bvh2 ORDERED) */
     int num_cus;
     /* device allocations */
-    void* d_nodes4; void* d_cnodes4; void* d_wnodes8; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
+    void* d_nodes4; void* d_cnodes4; void* d_wnodes8; void* d_objs; void* d_shapes; void* d_nodes2; void* d_bnodes2; void* d_bnodes2w; void* d_bnodes2wc; void* d_cell_start; void* d_cell_items; void* d_cell_dist; void* d_cell_objs;
     unsigned long long* d_counters;
     Scratch own[CRT_SLOTS];   /* allocated by crt_scene_create (perm / cells may grow); launch k uses own[k % CRT_SLOTS] */
     unsigned long long slot_last[CRT_SLOTS];   /* launch number (seq) of the last launch through each set, 0 = none yet */
@@ -113,6 +113,7 @@ struct crt_scene {
     unsigned root_word2;      /* BVH: root in k_bvh2's child-word form */
     unsigned root_word2w;     /* ... and in the collapsed (four-box) records */
     bool bvh2_wide;           /* the collapsed records exist and the ordered walk may use them */
+    bool bvh2_wcomp;          /* ... and so does their 64-byte conservative copy (walked when `compress` is on; CRT_BVH2_WCOMP=0: never) */
     bool binning; BinGrid bin_grid; bool bin_grid_valid;
     hipStream_t chunk_stream[2]; bool chunk_streams_valid;
 };
@@ -346,6 +347,68 @@ bool bvh2_collapse(const crt_scene_desc* desc, int depth, std::vector<float4>& b
     return true;
 }
 
+/* The collapsed records once more in the QBVH's 64-byte conservative layout (see the cnodes above crt_scene_create's copy of them):
+ * per record a frame (origin, scale per axis) and per slot and plane one byte, rounded OUTWARD and checked in double; an empty
+ * slot keeps an inverted box.  False (and nothing made) when a box is not finite. */
+bool bvh2_compress(const std::vector<float4>& b2w, std::vector<uint32_t>& out)
+{
+    out.clear();
+    const size_t nrec = b2w.size() / 8;
+    if (nrec == 0 || nrec >= ((size_t)1 << 26)) return false;       /* record index << 6 is a 32-bit byte offset */
+    out.assign(nrec * 16, 0u);
+    for (size_t r = 0; r < nrec; r++) {
+        const float4* q = &b2w[r * 8];
+        float bx[6][4];
+        for (int k = 0; k < 6; k++) { bx[k][0] = q[k].x; bx[k][1] = q[k].y; bx[k][2] = q[k].z; bx[k][3] = q[k].w; }
+        unsigned wd[4]; { float wf[4] = { q[6].x, q[6].y, q[6].z, q[6].w }; memcpy(wd, wf, 16); }
+        float lo[3] = { CRT_TMAX, CRT_TMAX, CRT_TMAX }, hi[3] = { -CRT_TMAX, -CRT_TMAX, -CRT_TMAX };
+        bool valid[4], any = false;
+        for (int c = 0; c < 4; c++) {
+            valid[c] = wd[c] != 0xFFFFFFFFu;
+            if (!valid[c]) continue;
+            for (int k = 0; k < 3; k++) {
+                const float mn = bx[k][c], mx = bx[3 + k][c];
+                if (!(fabsf(mn) < 1.0e30f) || !(fabsf(mx) < 1.0e30f)) { out.clear(); return false; }
+                if (mn > mx) valid[c] = false;                       /* an inverted box is never hit: keep it that way */
+            }
+            if (!valid[c]) continue;
+            for (int k = 0; k < 3; k++) { if (bx[k][c] < lo[k]) lo[k] = bx[k][c]; if (bx[3 + k][c] > hi[k]) hi[k] = bx[3 + k][c]; }
+            any = true;
+        }
+        if (!any) { lo[0] = lo[1] = lo[2] = 0.0f; hi[0] = hi[1] = hi[2] = 0.0f; }
+        float scale[3];
+        for (int k = 0; k < 3; k++) {
+            float sc = (float)(((double)hi[k] - (double)lo[k]) / 255.0);
+            while ((double)lo[k] + 255.0 * (double)sc < (double)hi[k]) sc = nextafterf(sc, CRT_TMAX);
+            scale[k] = sc;
+        }
+        uint32_t* o = &out[r * 16];
+        memcpy(&o[0], &lo[0], 4); memcpy(&o[1], &lo[1], 4); memcpy(&o[2], &lo[2], 4);
+        memcpy(&o[3], &scale[0], 4); memcpy(&o[4], &scale[1], 4); memcpy(&o[5], &scale[2], 4);
+        for (int k = 0; k < 3; k++) {
+            uint32_t lo_word = 0, hi_word = 0;
+            for (int c = 0; c < 4; c++) {
+                int qlo = 255, qhi = 0;                              /* empty slot: an inverted compressed box */
+                if (valid[c]) {
+                    const double mn = bx[k][c], mx = bx[3 + k][c], og = lo[k], sc = scale[k];
+                    if (sc > 0.0) {
+                        qlo = (int)floor((mn - og) / sc); if (qlo > 255) qlo = 255; if (qlo < 0) qlo = 0;
+                        while (qlo > 0 && og + qlo * sc > mn) qlo--;
+                        qhi = (int)ceil((mx - og) / sc); if (qhi < 0) qhi = 0; if (qhi > 255) qhi = 255;
+                        while (qhi < 255 && og + qhi * sc < mx) qhi++;
+                        if (og + qlo * sc > mn || og + qhi * sc < mx) { out.clear(); return false; }
+                    } else { qlo = 0; qhi = 0; }
+                }
+                lo_word |= (uint32_t)qlo << (8 * c);
+                hi_word |= (uint32_t)qhi << (8 * c);
+            }
+            o[6 + k] = lo_word; o[9 + k] = hi_word;
+        }
+        for (int c = 0; c < 4; c++) o[12 + c] = wd[c];
+    }
+    return true;
+}
+
 int validate_desc(const crt_scene_desc* d, int* d4, int* d2)
 {
     if (!d || d->num_obj < 0 || d->num_non_grid_obj < 0 || d->num_non_grid_obj > d->num_obj) return CRT_E_INVALID;
@@ -433,7 +496,7 @@ void free_scene(crt_scene* s)
 {
     if (!s) return;
     void* ptrs[] = { s->d_nodes4, s->d_cnodes4, s->d_wnodes8, s->d_objs, s->d_shapes, s->d_nodes2, s->d_cell_start, s->d_cell_items, s->d_cell_dist, s->d_cell_objs,
-                     s->d_bnodes2, s->d_bnodes2w, s->d_counters };
+                     s->d_bnodes2, s->d_bnodes2w, s->d_bnodes2wc, s->d_counters };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < CRT_SLOTS; k++) {
         void* q[] = { s->own[k].queue_head, s->own[k].ovf_word, s->own[k].ovf_key, s->own[k].bin_hist, s->own[k].bin_cursor, s->own[k].perm, s->own[k].cells, s->own[k].fb_list };
@@ -683,7 +746,11 @@ int dispatch_closest(crt_scene* s, const LaunchArgs& la, hipStream_t st, LaunchO
                          }
                          return exact ? launch(s, k_bvh4_closest<TRI_ONLY, COUNT, true>, la, st, o)
                                       : launch(s, k_bvh4_closest<TRI_ONLY, COUNT, false>, la, st, o);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true>, la, st, o);
+    case CRT_ACCEL_BVH:  /* the conservative records: triangle-only scenes, as for the QBVH -- a triangle's box is padded (K_FLAT_AABB) far beyond any
+                          * rounding, so a ray that hits it passes the reference's own box tests; a flat RECTANGLE's box is not, the reference
+                          * misses such hits, and a wider box would find them */
+                         if (TRI_ONLY && !exact && s->bvh2_wide && s->bvh2_wcomp && s->compress) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true, true>, la, st, o);
+                         if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true, true>, la, st, o);
                          if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, false, false, true>, la, st, o);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, false, true>, la, st, o)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, false, false>, la, st, o);
@@ -712,7 +779,8 @@ int dispatch_shadow(crt_scene* s, const LaunchArgs& la, hipStream_t st, unsigned
     switch (s->dev.accel) {
     case CRT_ACCEL_BVH4: if (TRI_ONLY && s->compress && s->cnodes_valid) return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT, true>, la, st, o);
                          return launch(s, k_bvh4_shadow<TRI_ONLY, COUNT>, la, st, o);
-    case CRT_ACCEL_BVH:  if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true>, la, st, o);
+    case CRT_ACCEL_BVH:  if (TRI_ONLY && !exact && s->bvh2_wide && s->bvh2_wcomp && s->compress) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true, true>, la, st, o);
+                         if (!exact && s->bvh2_wide) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true, true>, la, st, o);
                          if (!exact && s->bvh2_ordered) return launch(s, k_bvh2<TRI_ONLY, COUNT, true, false, true>, la, st, o);
                          return exact ? launch(s, k_bvh2<TRI_ONLY, COUNT, true, true>, la, st, o)
                                       : launch(s, k_bvh2<TRI_ONLY, COUNT, true, false>, la, st, o);
@@ -955,6 +1023,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
         }
         /* k_bvh2's layout: inner nodes only, renumbered in index order, each with both child boxes */
         std::vector<float4> b2, b2w;
+        std::vector<uint32_t> b2wc;
         if (desc->accel == CRT_ACCEL_BVH && desc->num_nodes2 > 0) {
             std::vector<int> inner_id((size_t)desc->num_nodes2, -1);
             int n_inner = 0;
@@ -984,6 +1053,8 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
                 e = getenv("CRT_BVH2_WIDE");
                 s->bvh2_wide = s->bvh2_ordered && !(e && atoi(e) == 0) && bvh2_collapse(desc, d2, b2w);
                 if (!s->bvh2_wide) b2w.clear();
+                e = getenv("CRT_BVH2_WCOMP");
+                s->bvh2_wcomp = s->bvh2_wide && !(e && atoi(e) == 0) && bvh2_compress(b2w, b2wc);
                 s->root_word2w = 0u;
             }
             for (int a = 0; a < 3; a++) { s->dev.root_bmin[a] = desc->nodes2[0].bmin[a]; s->dev.root_bmax[a] = desc->nodes2[0].bmax[a]; }
@@ -1011,7 +1082,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
             if (e && atoi(e) == 0) for (size_t c = 0; c < cd.size(); c++) if (cd[c] > 1) cd[c] = 1;
         }
         if ((rc = upload(&s->d_objs, objs)) != CRT_OK || (rc = upload(&s->d_nodes4, n4)) != CRT_OK || (rc = upload(&s->d_cnodes4, cn4)) != CRT_OK || (rc = upload(&s->d_wnodes8, w8)) != CRT_OK ||
-            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_bnodes2w, b2w)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
+            (rc = upload(&s->d_nodes2, n2)) != CRT_OK || (rc = upload(&s->d_bnodes2, b2)) != CRT_OK || (rc = upload(&s->d_bnodes2w, b2w)) != CRT_OK || (rc = upload(&s->d_bnodes2wc, b2wc)) != CRT_OK || (rc = upload(&s->d_shapes, shapes)) != CRT_OK ||
             (rc = upload(&s->d_cell_start, cs)) != CRT_OK || (rc = upload(&s->d_cell_items, ci)) != CRT_OK ||
             (rc = upload(&s->d_cell_dist, cd)) != CRT_OK || (!co.empty() && (rc = upload(&s->d_cell_objs, co)) != CRT_OK)) {
             free_scene(s);
@@ -1075,6 +1146,7 @@ int crt_scene_create(int device, const crt_scene_desc* desc, crt_scene** out)
     dv.root_word = (desc->accel == CRT_ACCEL_BVH4 && desc->num_nodes4 > 0) ? ((unsigned)(desc->nodes4[0].axis & 0x03) << 28) : 0u;
     if (desc->accel == CRT_ACCEL_BVH) dv.root_word = s->root_word2;
     dv.bnodes2w = (const float4*)s->d_bnodes2w;
+    dv.bnodes2wc = (const uint4*)s->d_bnodes2wc;
     dv.root_word_w = s->root_word2w;
     dv.bnodes2 = (const float4*)s->d_bnodes2;
     *out = s;

@@ -1178,9 +1178,14 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_none_shadow(DevScene sc, LaunchAr
 /* WIDE (with ORDERED): rays without NaN in their slab arithmetic walk the tree two levels at a time through the collapsed
  * records (sc.bnodes2w: four boxes per visit, the hit ones sorted by entry t, nearest first); the others -- a zero or
  * non-finite direction component, a non-finite origin -- walk the two-box records as before, lane by lane. */
-template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false, bool ORDERED = false, bool WIDE = false>
+/* WCOMP (with WIDE): the collapsed records are read from their 64-byte conservative copy (sc.bnodes2wc: the QBVH's compressed-node
+ * layout, 4 x 16 bytes per visit instead of 7) -- every box of it contains the record's box, so a superset of the reference's
+ * subtrees is walked, with entry distances that are never too large; the answer does not depend on the order of the walk (ORDERED
+ * above), so it is the same.  Rays whose fma-form slab arithmetic could overflow (|1/d| >= 1e6) walk the two-box records. */
+template <bool TRI_ONLY, bool COUNT, bool SHADOW, bool EXACT = false, bool ORDERED = false, bool WIDE = false, bool WCOMP = false>
 __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
 {
+    static_assert(!WCOMP || (WIDE && ORDERED && !EXACT), "the conservative records belong to the collapsed, ordered walk");
     resolve_count(la);
     __shared__ StackEntry s_stack[CRT_LDS_DEPTH][CRT_BLOCK];
     const unsigned gtid = blockIdx.x * CRT_BLOCK + threadIdx.x;
@@ -1218,6 +1223,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                 if (WIDE) {
                     wide = fabsf(ia) < CRT_TMAX && fabsf(ib) < CRT_TMAX && fabsf(ic) < CRT_TMAX && ia != 0.0f && ib != 0.0f && ic != 0.0f &&
                            fabsf(ray.ox) < 1.0e30f && fabsf(ray.oy) < 1.0e30f && fabsf(ray.oz) < 1.0e30f;
+                    if (WCOMP) wide = wide && fabsf(ia) < 1.0e6f && fabsf(ib) < 1.0e6f && fabsf(ic) < 1.0e6f;
                     if (wide) cur = sc.root_word_w;
                 }
                 walking = false;
@@ -1243,6 +1249,23 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                         if (t < CRT_TMAX && (t < best_t || (t == best_t && idx > best_idx))) { best_t = t; best = h; best_idx = idx; }
                     }
                     else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
+                } else if (WCOMP && wide) {
+                    if (COUNT) c_nodes += 4;
+                    float key[4];
+                    uint4 wds;
+                    cnode_keys(sc.bnodes2wc, cur << 6, ray, ia, ib, ic, ray.dx >= 0.0f, ray.dy >= 0.0f, ray.dz >= 0.0f, &key[0], &key[1], &key[2], &key[3], &wds);
+                    unsigned wd[4] = { wds.x, wds.y, wds.z, wds.w };
+                    asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]));      /* the words of the one 16-byte load (see node_step) */
+                    const float pinf = __builtin_huge_valf();
+#pragma unroll
+                    for (int c = 0; c < 4; c++) key[c] = (key[c] < CRT_TMAX && !(key[c] > best_t)) ? key[c] : pinf;   /* cnode_key: TMAX = missed */
+#define CRT_CSWAP(a, b) { if (key[b] < key[a]) { const float tk = key[a]; key[a] = key[b]; key[b] = tk; const unsigned tw = wd[a]; wd[a] = wd[b]; wd[b] = tw; } }
+                    CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
+#undef CRT_CSWAP
+                    if (key[3] < pinf) st.push(wd[3], key[3]);
+                    if (key[2] < pinf) st.push(wd[2], key[2]);
+                    if (key[1] < pinf) st.push(wd[1], key[1]);
+                    if (key[0] < pinf) { cur = wd[0]; need_pop = false; }
                 } else if (WIDE && wide) {
                     const float4* nd = sc.bnodes2w + (size_t)cur * 8;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];

@@ -270,7 +270,7 @@ def _tie_scene():
 @pytest.mark.parametrize("scene", ["blobs", "ties"])
 def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
     """The device-side choices the host makes at scene creation -- node order in memory (QBVH), nearer-child-first pruned
-    walk (binary BVH), empty-cell skipping by distance field (grid), the tail-splitting walk for small batches (QBVH) -- are
+    walk (binary BVH) and the 64-byte conservative copy of its collapsed records, empty-cell skipping by distance field (grid), the tail-splitting walk for small batches (QBVH) -- are
     invisible in the results: each is switched
     through its environment knob and compared bit for bit with the other setting and with the oracle, on a scene whose
     every hit is a three-way exact tie as well."""
@@ -280,6 +280,7 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
                                   (api.ACCEL_BVH4, "CRT_TAIL_SPLIT_MAX", ("0", "100000000")),
                                   (api.ACCEL_BVH, "CRT_BVH2_ORDERED", ("0", "1")),
                                   (api.ACCEL_BVH, "CRT_BVH2_WIDE", ("0", "1")),
+                                  (api.ACCEL_BVH, "CRT_BVH2_WCOMP", ("0", "1")),
                                   (api.ACCEL_GRID, "CRT_GRID_SKIP", ("0", "1"))):
         built = api.BuiltScene(si, accel)
         o = ol.OracleScene(si, accel, sort_mode=0)
@@ -310,6 +311,8 @@ def test_walk_and_layout_knobs_leave_every_record_alone(scene, monkeypatch):
             assert len(set(cells)) == 1
         if knob == "CRT_BVH2_ORDERED" and scene == "blobs":   # nearer child first tests fewer boxes
             assert cells[1] < cells[0]
+        if knob == "CRT_BVH2_WCOMP":                      # conservative records: a superset of the boxes, a few per cent more
+            assert cells[0] <= cells[1] <= 1.15 * cells[0]
 
 
 @pytest.mark.parametrize("accel", ACCELS)
