@@ -1239,17 +1239,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
         if (alive) {
             if (walking) {
                 bool need_pop = true;
-                if (cur & CRT_LEAF_BIT) {
-                    DHit h;
-                    const float t = dev_object<TRI_ONLY>(sc, (int)(cur & ~CRT_LEAF_BIT), ray, SHADOW, &h);
-                    if (COUNT) c_prims++;
-                    if (SHADOW) { if (t < best_t) best_t = t; }
-                    else if (ORDERED) {
-                        const unsigned idx = cur & ~CRT_LEAF_BIT;
-                        if (t < CRT_TMAX && (t < best_t || (t == best_t && idx > best_idx))) { best_t = t; best = h; best_idx = idx; }
-                    }
-                    else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
-                } else if (WCOMP && wide) {
+                /* WCOMP: a node step whose nearest box is a leaf tests that leaf's object in the same iteration (the lane would do
+                 * nothing else in the next one): the leaf test below runs after the node step instead of in place of it */
+                const bool leaf_first = (cur & CRT_LEAF_BIT) != 0u;
+                if (!leaf_first && WCOMP && wide) {
                     if (COUNT) c_nodes += 4;
                     float key[4];
                     uint4 wds;
@@ -1266,6 +1259,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                     if (key[2] < pinf) st.push(wd[2], key[2]);
                     if (key[1] < pinf) st.push(wd[1], key[1]);
                     if (key[0] < pinf) { cur = wd[0]; need_pop = false; }
+                } else if (leaf_first) {
                 } else if (WIDE && wide) {
                     const float4* nd = sc.bnodes2w + (size_t)cur * 8;
                     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
@@ -1312,6 +1306,18 @@ __global__ __launch_bounds__(CRT_BLOCK) void k_bvh2(DevScene sc, LaunchArgs la)
                         if (rv) st.push(rw, rkey);
                         cur = lw; need_pop = false;
                     } else if (rv) { cur = rw; need_pop = false; }
+                }
+                if (leaf_first || (WCOMP && wide && !need_pop && (cur & CRT_LEAF_BIT))) {
+                    DHit h;
+                    const float t = dev_object<TRI_ONLY>(sc, (int)(cur & ~CRT_LEAF_BIT), ray, SHADOW, &h);
+                    if (COUNT) c_prims++;
+                    if (SHADOW) { if (t < best_t) best_t = t; }
+                    else if (ORDERED) {
+                        const unsigned idx = cur & ~CRT_LEAF_BIT;
+                        if (t < CRT_TMAX && (t < best_t || (t == best_t && idx > best_idx))) { best_t = t; best = h; best_idx = idx; }
+                    }
+                    else if (t <= best_t && t < CRT_TMAX) { best_t = t; best = h; }    /* right / later wins ties */
+                    need_pop = true;
                 }
                 if (need_pop) {
                     walking = false;
